@@ -1,0 +1,886 @@
+// C ABI of liblanecv.so (declared in include/lanecv.h): contexts, the per-op
+// cv2-shaped entry points and the batched lane pipeline.  Host logic only; the
+// kernels live in kernels_*.hip.
+#include "../../include/lanecv.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+using namespace lanecv;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(LC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int MAX_DIM = 8192;       // 16.16 walk arithmetic and the packed (x | y << 16) points need this bound
+constexpr int HYST_CHUNK = 4;       // hysteresis rounds enqueued between two convergence checks
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T) + 64);
+        if (e != hipSuccess) { p = nullptr; return fail(LC_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); }
+        n = count;
+        return LC_OK;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    ~DevBuf() { release(); }
+};
+
+// ---- Hough geometry (HoughLinesP narrows rho/theta to float first) ---------
+struct HoughGeo {
+    int numangle = 0, numrho = 0;
+    std::vector<AngleEntry> tab;
+};
+
+int hough_geo(int w, int h, double rho_d, double theta_d, HoughGeo &hg) {
+    if (!(rho_d > 0) || !(theta_d > 0)) return fail(LC_EINVAL, "HoughLinesP: rho and theta must be positive");
+    const float rho = (float)rho_d, theta = (float)theta_d;
+    const float irho = 1 / rho;
+    // computeNumangle(0, pi, theta)
+    int na = (int)std::floor((M_PI - 0.0) / (double)theta) + 1;
+    if (na > 1 && std::fabs(M_PI - (na - 1) * (double)theta) < (double)theta / 2) --na;
+    const int nr = (int)lrintf((float)((w + h) * 2 + 1) / rho);
+    if (na < 1 || nr < 1) return fail(LC_EINVAL, "HoughLinesP: degenerate accumulator %d x %d", na, nr);
+    hg.numangle = na;
+    hg.numrho = nr;
+    hg.tab.resize(na);
+    for (int n = 0; n < na; n++) {
+        AngleEntry e;
+        e.c = (float)(std::cos((double)n * theta) * irho);
+        e.s = (float)(std::sin((double)n * theta) * irho);
+        const float a = -e.s, b = e.c;
+        if (std::fabs(a) > std::fabs(b)) {
+            e.xflag = 1;
+            e.dmaj = a > 0 ? 1 : -1;
+            e.dmin = (int)lrintf(b * (1 << 16) / std::fabs(a));
+        } else {
+            e.xflag = 0;
+            e.dmaj = b > 0 ? 1 : -1;
+            e.dmin = (int)lrintf(a * (1 << 16) / std::fabs(b));
+        }
+        e.pad = 0;
+        hg.tab[n] = e;
+    }
+    return LC_OK;
+}
+
+// ---- device working set for up to B frames of one size ---------------------
+struct Work {
+    Geo g{};
+    int B = 0;
+    size_t npix = 0;
+    bool inter = false;
+    DevBuf<uint8_t> bgr, gray, blur, edges, masked;
+    DevBuf<uint64_t> planeS, planeW, rowplane;
+    DevBuf<int> act, nact, rowcount, rowoff, npoints, segcount, status;
+    DevBuf<uint32_t> nz;
+    int nz_cap = 0;
+    DevBuf<int32_t> acc_full, acc_ppht, seg;
+    DevBuf<AngleEntry> tab;
+    HoughGeo hg;
+    double rho = 0, theta = 0;
+    int seg_cap = 0;
+
+    int init_images(int W, int H, int batch, bool own_input, bool intermediates, bool colour) {
+        g = make_geo(W, H);
+        B = batch;
+        npix = (size_t)W * H;
+        inter = intermediates;
+        int rc;
+        if (own_input && (rc = bgr.alloc((size_t)B * npix * (colour ? 3 : 1)))) return rc;
+        if (intermediates) {
+            if ((rc = gray.alloc((size_t)B * npix))) return rc;
+            if ((rc = blur.alloc((size_t)B * npix))) return rc;
+            if ((rc = edges.alloc((size_t)B * npix))) return rc;
+        }
+        if ((rc = masked.alloc((size_t)B * npix))) return rc;
+        if ((rc = planeS.alloc((size_t)B * g.plane_words()))) return rc;
+        if ((rc = planeW.alloc((size_t)B * g.plane_words()))) return rc;
+        if ((rc = rowplane.alloc((size_t)B * g.rowplane_words()))) return rc;
+        if ((rc = act.alloc((size_t)B * g.TX * g.TY))) return rc;
+        if ((rc = nact.alloc(HYST_CHUNK + 2))) return rc;
+        if ((rc = rowcount.alloc((size_t)B * H))) return rc;
+        if ((rc = rowoff.alloc((size_t)B * H))) return rc;
+        if ((rc = npoints.alloc(B))) return rc;
+        if ((rc = segcount.alloc(B))) return rc;
+        if ((rc = status.alloc(1))) return rc;
+        return LC_OK;
+    }
+    int init_points(int cap) {
+        nz_cap = cap;
+        return nz.alloc((size_t)B * cap);
+    }
+    int init_hough(double rho_, double theta_, int segcap, bool full, bool ppht, hipStream_t st) {
+        int rc;
+        if (rho_ != rho || theta_ != theta || hg.numangle == 0) {
+            if ((rc = hough_geo(g.W, g.H, rho_, theta_, hg))) return rc;
+            rho = rho_; theta = theta_;
+            if ((rc = tab.alloc(hg.numangle))) return rc;
+            HIP_TRY(hipMemcpyAsync(tab.p, hg.tab.data(), sizeof(AngleEntry) * hg.numangle, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            acc_full.release();
+            acc_ppht.release();
+        }
+        size_t accn = (size_t)B * hg.numangle * hg.numrho;
+        if (full && acc_full.n < accn && (rc = acc_full.alloc(accn))) return rc;
+        if (ppht && acc_ppht.n < accn && (rc = acc_ppht.alloc(accn))) return rc;
+        if (ppht && (seg_cap != segcap || !seg.p)) {
+            seg_cap = segcap;
+            if ((rc = seg.alloc((size_t)B * segcap * 4))) return rc;
+        }
+        return LC_OK;
+    }
+};
+
+// Runs hysteresis rounds [r0, r0 + n) on the stream; nact_dev[k] (k = 1..n) receives
+// the number of wake-ups made by round r0 + k - 1.
+void enqueue_hyst(Work &w, int nframes, int r0, int n, hipStream_t st) {
+    (void)hipMemsetAsync(w.nact.p, 0, sizeof(int) * (HYST_CHUNK + 2), st);
+    for (int r = r0; r < r0 + n; r++)
+        launch_hyst_round(w.g, nframes, r, w.planeS.p, w.planeW.p, w.act.p, w.nact.p - r0, st);
+}
+
+bool chunk_converged(const int *nact_host, int n) {
+    for (int k = 1; k <= n; k++)
+        if (nact_host[k] == 0) return true;
+    return false;
+}
+
+// Synchronous hysteresis to the fixed point (used by the per-op calls).
+int hysteresis_sync(Work &w, int nframes, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(w.act.p, 0, sizeof(int) * (size_t)w.B * w.g.TX * w.g.TY, st));
+    int host[HYST_CHUNK + 2];
+    for (int r0 = 0;; r0 += HYST_CHUNK) {
+        enqueue_hyst(w, nframes, r0, HYST_CHUNK, st);
+        HIP_TRY(hipMemcpyAsync(host, w.nact.p, sizeof host, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (chunk_converged(host, HYST_CHUNK)) return LC_OK;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+struct lc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Work work;            // batch-1 working set of the per-op calls, keyed by (w, h)
+    int work_w = 0, work_h = 0;
+    DevBuf<uint8_t> tmpA, tmpB, tmpC, tmpD;
+};
+
+namespace {
+
+int ctx_bind(lc_ctx *ctx) {
+    if (!ctx) return fail(LC_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return LC_OK;
+}
+
+int check_image(const void *p, int w, int h, size_t stride, size_t min_stride, const char *what) {
+    if (!p) return fail(LC_EINVAL, "%s: null image pointer", what);
+    if (w <= 0 || h <= 0) return fail(LC_EINVAL, "%s: empty image %d x %d", what, w, h);
+    if (w > MAX_DIM || h > MAX_DIM) return fail(LC_EUNSUPPORTED, "%s: images above %d pixels a side are not supported", what, MAX_DIM);
+    if (stride < min_stride) return fail(LC_EINVAL, "%s: stride %zu below row size %zu", what, stride, min_stride);
+    return LC_OK;
+}
+
+int ctx_work(lc_ctx *ctx, int w, int h) {
+    if (ctx->work_w == w && ctx->work_h == h) return LC_OK;
+    ctx->work_w = ctx->work_h = 0;
+    ctx->work = Work();
+    int rc;
+    if ((rc = ctx->work.init_images(w, h, 1, true, false, true))) return rc;
+    if ((rc = ctx->work.init_points(w * h))) return rc;
+    size_t n = (size_t)w * h;
+    if ((rc = ctx->tmpA.alloc(n)) || (rc = ctx->tmpB.alloc(n)) || (rc = ctx->tmpC.alloc(n)) || (rc = ctx->tmpD.alloc(n))) return rc;
+    ctx->work_w = w; ctx->work_h = h;
+    return LC_OK;
+}
+
+int up2d(void *dst, const void *src, size_t row_bytes, int h, size_t stride, hipStream_t st) {
+    HIP_TRY(hipMemcpy2DAsync(dst, row_bytes, src, stride, row_bytes, h, hipMemcpyHostToDevice, st));
+    return LC_OK;
+}
+int down2d(void *dst, size_t stride, const void *src, size_t row_bytes, int h, hipStream_t st) {
+    HIP_TRY(hipMemcpy2DAsync(dst, stride, src, row_bytes, row_bytes, h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LC_OK;
+}
+
+// non-zero image already in tmpA -> point list of work (row-major order) and row plane
+int points_from_bytes(lc_ctx *ctx, int *npoints_host) {
+    Work &w = ctx->work;
+    hipStream_t st = ctx->stream;
+    launch_pack_nonzero(ctx->tmpA.p, w.g, 1, w.rowplane.p, w.rowcount.p, st);
+    launch_rowscan(w.g, 1, w.rowcount.p, w.rowoff.p, w.npoints.p, st);
+    launch_scatter(w.g, 1, w.rowplane.p, w.rowoff.p, w.nz.p, w.nz_cap, st);
+    if (npoints_host) {
+        HIP_TRY(hipMemcpyAsync(npoints_host, w.npoints.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return LC_OK;
+}
+
+// ---- polygon set-up on the host (drawing.cpp: clipLine, LineIterator, CollectPolyEdges) ----
+struct P64 { long long x, y; };
+
+bool clip_line(long long width, long long height, P64 &p1, P64 &p2) {
+    const long long right = width - 1, bottom = height - 1;
+    if (width <= 0 || height <= 0) return false;
+    long long &x1 = p1.x, &y1 = p1.y, &x2 = p2.x, &y2 = p2.y;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (x2 - x1) / (y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (x2 - x1) / (y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (y2 - y1) / (x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (y2 - y1) / (x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+bool inside(const P64 &p, int w, int h) {
+    return (unsigned long long)p.x < (unsigned long long)w && (unsigned long long)p.y < (unsigned long long)h;
+}
+
+// the clipped, left-to-right 8-connected segment LineIterator would walk
+bool make_line(int w, int h, P64 a, P64 b, LineDev &L) {
+    if (!inside(a, w, h) || !inside(b, w, h)) {
+        if (!clip_line(w, h, a, b)) return false;
+    }
+    int dx = (int)(b.x - a.x), dy = (int)(b.y - a.y);
+    int sx = 1, sy = 1;
+    if (dx < 0) { dx = -dx; dy = -dy; a = b; }
+    if (dy < 0) { dy = -dy; sy = -1; }
+    L.x0 = (int)a.x; L.y0 = (int)a.y;
+    L.vert = dy > dx;
+    if (L.vert) { L.dmaj = sy; L.dmin = sx; L.dmajor_len = dy; L.dminor_len = dx; }
+    else        { L.dmaj = sx; L.dmin = sy; L.dmajor_len = dx; L.dminor_len = dy; }
+    L.count = L.dmajor_len + 1;
+    return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int lc_version(void) { return 100; }
+
+const char *lc_last_error(void) { return g_err.c_str(); }
+
+int lc_create(int device, lc_ctx **out) {
+    if (!out) return fail(LC_EINVAL, "lc_create: null output");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(LC_EHIP, "lc_create: no HIP device available (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= ndev) return fail(LC_EINVAL, "lc_create: device %d out of range [0, %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    lc_ctx *ctx = new lc_ctx();
+    ctx->device = device;
+    hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete ctx; return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
+    *out = ctx;
+    return LC_OK;
+}
+
+int lc_destroy(lc_ctx *ctx) {
+    if (!ctx) return LC_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+    return LC_OK;
+}
+
+int lc_host_alloc_pinned(size_t bytes, void **out) {
+    if (!out) return fail(LC_EINVAL, "null output");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return LC_OK;
+}
+
+int lc_host_free(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return LC_OK;
+}
+
+int lc_cvt_gray(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, int code, uint8_t *dst, size_t dst_stride) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if (code != LC_COLOR_BGR2GRAY && code != LC_COLOR_RGB2GRAY)
+        return fail(LC_EUNSUPPORTED, "cvtColor: only COLOR_BGR2GRAY (6) and COLOR_RGB2GRAY (7) are supported, got %d", code);
+    if ((rc = check_image(src, w, h, src_stride, 3 * (size_t)w, "cvtColor src"))) return rc;
+    if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "cvtColor dst"))) return rc;
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    if ((rc = up2d(ctx->work.bgr.p, src, 3 * (size_t)w, h, src_stride, ctx->stream))) return rc;
+    launch_gray(ctx->work.bgr.p, w, h, 1, code, ctx->tmpA.p, ctx->stream);
+    return down2d(dst, dst_stride, ctx->tmpA.p, w, h, ctx->stream);
+}
+
+int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, uint8_t *dst, size_t dst_stride) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(src, w, h, src_stride, (size_t)w, "GaussianBlur src"))) return rc;
+    if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "GaussianBlur dst"))) return rc;
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    if ((rc = up2d(ctx->tmpA.p, src, w, h, src_stride, ctx->stream))) return rc;
+    launch_blur5(ctx->tmpA.p, w, h, 1, ctx->tmpB.p, ctx->stream);
+    return down2d(dst, dst_stride, ctx->tmpB.p, w, h, ctx->stream);
+}
+
+int lc_canny(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, double t1, double t2, uint8_t *dst,
+             size_t dst_stride) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(src, w, h, src_stride, (size_t)w, "Canny image"))) return rc;
+    if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "Canny edges"))) return rc;
+    if (!(t1 == t1) || !(t2 == t2)) return fail(LC_EINVAL, "Canny: NaN threshold");
+    if (t1 > t2) std::swap(t1, t2);
+    if (t2 > 1e9) t2 = 1e9;
+    if (t1 > 1e9) t1 = 1e9;
+    if (t1 < -1e9) t1 = -1e9;
+    if (t2 < -1e9) t2 = -1e9;
+    const int low = (int)std::floor(t1), high = (int)std::floor(t2);
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    Work &wk = ctx->work;
+    if ((rc = up2d(ctx->tmpA.p, src, w, h, src_stride, ctx->stream))) return rc;
+    launch_front(ctx->tmpA.p, (size_t)w * h, 0, LC_COLOR_BGR2GRAY, false, wk.g, 1, low, high, wk.planeS.p, wk.planeW.p,
+                 nullptr, nullptr, ctx->stream);
+    if ((rc = hysteresis_sync(wk, 1, ctx->stream))) return rc;
+    launch_finalize(wk.g, 1, wk.planeS.p, nullptr, ctx->tmpB.p, nullptr, nullptr, nullptr, ctx->stream);
+    return down2d(dst, dst_stride, ctx->tmpB.p, w, h, ctx->stream);
+}
+
+int lc_and(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size_t b_stride, const uint8_t *mask,
+           size_t mask_stride, uint8_t *dst, size_t dst_stride, int w, int h) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(a, w, h, a_stride, (size_t)w, "bitwise_and src1"))) return rc;
+    if ((rc = check_image(b, w, h, b_stride, (size_t)w, "bitwise_and src2"))) return rc;
+    if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "bitwise_and dst"))) return rc;
+    if (mask && (rc = check_image(mask, w, h, mask_stride, (size_t)w, "bitwise_and mask"))) return rc;
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    if ((rc = up2d(ctx->tmpA.p, a, w, h, a_stride, ctx->stream))) return rc;
+    if ((rc = up2d(ctx->tmpB.p, b, w, h, b_stride, ctx->stream))) return rc;
+    if (mask && (rc = up2d(ctx->tmpC.p, mask, w, h, mask_stride, ctx->stream))) return rc;
+    launch_and(ctx->tmpA.p, ctx->tmpB.p, mask ? ctx->tmpC.p : nullptr, ctx->tmpD.p, (size_t)w * h, ctx->stream);
+    return down2d(dst, dst_stride, ctx->tmpD.p, w, h, ctx->stream);
+}
+
+int lc_fill_poly(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride, const int32_t *pts, const int *npts, int ncontours,
+                 int color) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(img, w, h, stride, (size_t)w, "fillPoly img"))) return rc;
+    if (ncontours < 0 || (ncontours > 0 && (!pts || !npts))) return fail(LC_EINVAL, "fillPoly: bad contour arguments");
+    color = color < 0 ? 0 : (color > 255 ? 255 : color);
+    std::vector<PolyEdgeDev> edges;
+    std::vector<LineDev> lines;
+    const int32_t *v = pts;
+    for (int c = 0; c < ncontours; v += 2 * (size_t)npts[c], c++) {
+        const int count = npts[c];
+        if (count < 0) return fail(LC_EINVAL, "fillPoly: negative vertex count");
+        if (count == 0) continue;
+        P64 pt0 = {(long long)v[2 * (count - 1)] << 16, v[2 * (count - 1) + 1]}, pt1;
+        for (int i = 0; i < count; i++, pt0 = pt1) {
+            pt1.x = (long long)v[2 * i] << 16;
+            pt1.y = v[2 * i + 1];
+            P64 pt0c = pt0, pt1c = pt1;
+            P64 t0 = {(pt0.x + 32768) >> 16, pt0.y}, t1 = {(pt1.x + 32768) >> 16, pt1.y};
+            LineDev L;
+            if (make_line(w, h, t0, t1, L)) lines.push_back(L);
+            if (!inside(t0, w, h) || !inside(t1, w, h)) {
+                clip_line(w, h, t0, t1);
+                if (t0.y != t1.y) {
+                    pt0c.y = t0.y; pt1c.y = t1.y;
+                    pt0c.x = t0.x << 16; pt1c.x = t1.x << 16;
+                }
+            } else {
+                pt0c.x += 32768;
+                pt1c.x += 32768;
+            }
+            if (pt0.y == pt1.y) continue;
+            PolyEdgeDev e;
+            e.dx = (pt1c.x - pt0c.x) / (pt1c.y - pt0c.y);
+            if (pt0.y < pt1.y) { e.y0 = (int)pt0.y; e.y1 = (int)pt1.y; e.x = pt0c.x + (pt0.y - pt0c.y) * e.dx; }
+            else               { e.y0 = (int)pt1.y; e.y1 = (int)pt0.y; e.x = pt1c.x + (pt1.y - pt1c.y) * e.dx; }
+            edges.push_back(e);
+        }
+    }
+    if (edges.size() > 1024) return fail(LC_EUNSUPPORTED, "fillPoly: more than 1024 non-horizontal edges");
+    // FillEdgeCollection's early outs
+    bool spans = edges.size() >= 2;
+    int y_min = 0, y_max = 0;
+    if (spans) {
+        long long x_max = -1, x_min = INT64_MAX;
+        y_max = INT32_MIN; y_min = INT32_MAX;
+        for (const PolyEdgeDev &e : edges) {
+            long long x1 = e.x + (long long)(e.y1 - e.y0) * e.dx;
+            y_min = std::min(y_min, e.y0); y_max = std::max(y_max, e.y1);
+            x_min = std::min(x_min, std::min(e.x, x1)); x_max = std::max(x_max, std::max(e.x, x1));
+        }
+        if (y_max < 0 || y_min >= h || x_max < 0 || x_min >= ((long long)w << 16)) spans = false;
+        y_min = std::max(y_min, 0);
+        y_max = std::min(y_max, h);
+    }
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
+    DevBuf<PolyEdgeDev> de;
+    DevBuf<LineDev> dl;
+    if (!lines.empty()) {
+        if ((rc = dl.alloc(lines.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(dl.p, lines.data(), lines.size() * sizeof(LineDev), hipMemcpyHostToDevice, ctx->stream));
+        launch_draw_lines(ctx->tmpA.p, w, h, dl.p, (int)lines.size(), color, ctx->stream);
+    }
+    if (spans) {
+        if ((rc = de.alloc(edges.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(de.p, edges.data(), edges.size() * sizeof(PolyEdgeDev), hipMemcpyHostToDevice, ctx->stream));
+        launch_fill_spans(ctx->tmpA.p, w, h, de.p, (int)edges.size(), y_min, y_max, color, ctx->stream);
+    }
+    return down2d(img, stride, ctx->tmpA.p, w, h, ctx->stream);
+}
+
+int lc_rectangle_filled(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride, int x1, int y1, int x2, int y2, int color) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(img, w, h, stride, (size_t)w, "rectangle img"))) return rc;
+    color = color < 0 ? 0 : (color > 255 ? 255 : color);
+    if (x1 > x2) std::swap(x1, x2);
+    if (y1 > y2) std::swap(y1, y2);
+    x1 = std::max(x1, 0); y1 = std::max(y1, 0);
+    x2 = std::min(x2, w - 1); y2 = std::min(y2, h - 1);
+    if (x2 < x1 || y2 < y1) return LC_OK;
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
+    launch_fill_rect(ctx->tmpA.p, w, h, x1, y1, x2, y2, color, ctx->stream);
+    return down2d(img, stride, ctx->tmpA.p, w, h, ctx->stream);
+}
+
+int lc_hough_geometry(int w, int h, double rho, double theta, int *numangle, int *numrho) {
+    if (w <= 0 || h <= 0) return fail(LC_EINVAL, "empty image");
+    HoughGeo hg;
+    int rc = hough_geo(w, h, rho, theta, hg);
+    if (rc) return rc;
+    if (numangle) *numangle = hg.numangle;
+    if (numrho) *numrho = hg.numrho;
+    return LC_OK;
+}
+
+int lc_hough_accum(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, double rho, double theta, int32_t *acc,
+                   int acc_capacity, int *numangle, int *numrho) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(img, w, h, stride, (size_t)w, "hough image"))) return rc;
+    if (!acc) return fail(LC_EINVAL, "null accumulator");
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    Work &wk = ctx->work;
+    if ((rc = wk.init_hough(rho, theta, 1, true, false, ctx->stream))) return rc;
+    const int na = wk.hg.numangle, nr = wk.hg.numrho;
+    if (numangle) *numangle = na;
+    if (numrho) *numrho = nr;
+    if ((long long)acc_capacity < (long long)na * nr) return fail(LC_ECAP, "accumulator needs %d x %d int32", na, nr);
+    if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
+    if ((rc = points_from_bytes(ctx, nullptr))) return rc;
+    launch_vote(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.tab.p, na, nr, wk.acc_full.p, ctx->stream);
+    HIP_TRY(hipMemcpyAsync(acc, wk.acc_full.p, sizeof(int32_t) * (size_t)na * nr, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LC_OK;
+}
+
+int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, double rho, double theta, int threshold,
+                     double min_line_length, double max_line_gap, int32_t *out, int capacity, int *n) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(img, w, h, stride, (size_t)w, "HoughLinesP image"))) return rc;
+    if (!n || capacity < 0 || (capacity > 0 && !out)) return fail(LC_EINVAL, "HoughLinesP: bad output arguments");
+    *n = 0;
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    Work &wk = ctx->work;
+    const int cap = std::max(capacity, 1);
+    if ((rc = wk.init_hough(rho, theta, cap, false, true, ctx->stream))) return rc;
+    const int na = wk.hg.numangle, nr = wk.hg.numrho;
+    if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
+    if ((rc = points_from_bytes(ctx, nullptr))) return rc;
+    HIP_TRY(hipMemsetAsync(wk.acc_ppht.p, 0, sizeof(int32_t) * (size_t)na * nr, ctx->stream));
+    HIP_TRY(hipMemsetAsync(wk.status.p, 0, sizeof(int), ctx->stream));
+    launch_ppht(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, wk.acc_ppht.p, threshold,
+                (int)lrint(min_line_length), (int)lrint(max_line_gap), wk.seg.p, cap, wk.segcount.p, wk.status.p, ctx->stream);
+    int host[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&host[0], wk.segcount.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&host[1], wk.status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (host[1]) return fail(LC_EINVAL, "HoughLinesP: internal range error (status %d)", host[1]);
+    *n = host[0];
+    const int ncopy = std::min(host[0], capacity);
+    if (ncopy > 0) {
+        HIP_TRY(hipMemcpyAsync(out, wk.seg.p, sizeof(int32_t) * 4 * (size_t)ncopy, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (host[0] > capacity) return fail(LC_ECAP, "HoughLinesP found %d segments, capacity is %d", host[0], capacity);
+    return LC_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// batched pipeline
+// ---------------------------------------------------------------------------
+struct Slot {
+    Work w;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[8] = {};
+    int nframes = 0;
+    const uint8_t *input = nullptr;   // device pointer of the frames of the batch in flight
+    size_t input_bytes = 0;
+    bool busy = false, timed = false;
+    // pinned host staging
+    int *h_nact = nullptr, *h_status = nullptr, *h_segcount = nullptr;
+    int32_t *h_seg = nullptr;
+    int rounds_done = 0;
+};
+
+struct lc_pipe {
+    lc_ctx *ctx = nullptr;
+    lc_pipe_params p{};
+    Geo g{};
+    int low = 0, high = 0, line_length = 0, line_gap = 0;
+    DevBuf<uint64_t> roi_bits;
+    bool has_roi = false;
+    std::vector<Slot> slots;
+};
+
+namespace {
+
+enum { EV_START = 0, EV_UPLOADED, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END };
+
+void enqueue_back(lc_pipe *pp, Slot &s) {
+    Work &w = s.w;
+    const lc_pipe_params &p = pp->p;
+    const int n = s.nframes;
+    (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, s.st);
+    launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
+                    w.rowplane.p, w.rowcount.p, s.st);
+    (void)hipEventRecord(s.ev[EV_EDGE], s.st);
+    const bool hough = p.want_accumulator || p.want_segments;
+    if (hough) {
+        launch_rowscan(w.g, n, w.rowcount.p, w.rowoff.p, w.npoints.p, s.st);
+        launch_scatter(w.g, n, w.rowplane.p, w.rowoff.p, w.nz.p, w.nz_cap, s.st);
+    }
+    (void)hipEventRecord(s.ev[EV_POINTS], s.st);
+    if (p.want_accumulator)
+        launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, s.st);
+    (void)hipEventRecord(s.ev[EV_VOTE], s.st);
+    if (p.want_segments) {
+        (void)hipMemsetAsync(w.acc_ppht.p, 0, sizeof(int32_t) * (size_t)n * w.hg.numangle * w.hg.numrho, s.st);
+        (void)hipMemsetAsync(w.status.p, 0, sizeof(int), s.st);
+        launch_ppht(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
+                    p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p, s.st);
+    }
+    (void)hipEventRecord(s.ev[EV_LINES], s.st);
+    if (p.want_segments) {
+        (void)hipMemcpyAsync(s.h_segcount, w.segcount.p, sizeof(int) * n, hipMemcpyDeviceToHost, s.st);
+        (void)hipMemcpyAsync(s.h_seg, w.seg.p, sizeof(int32_t) * 4 * (size_t)n * w.seg_cap, hipMemcpyDeviceToHost, s.st);
+        (void)hipMemcpyAsync(s.h_status, w.status.p, sizeof(int), hipMemcpyDeviceToHost, s.st);
+    }
+    (void)hipEventRecord(s.ev[EV_END], s.st);
+}
+
+int enqueue_all(lc_pipe *pp, Slot &s) {
+    Work &w = s.w;
+    const lc_pipe_params &p = pp->p;
+    const int n = s.nframes;
+    HIP_TRY(hipMemsetAsync(w.act.p, 0, sizeof(int) * (size_t)n * w.g.TX * w.g.TY, s.st));
+    HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], s.st));
+    launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
+                 w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, s.st);
+    enqueue_hyst(w, n, 0, HYST_CHUNK, s.st);
+    s.rounds_done = HYST_CHUNK;
+    HIP_TRY(hipMemcpyAsync(s.h_nact, w.nact.p, sizeof(int) * (HYST_CHUNK + 2), hipMemcpyDeviceToHost, s.st));
+    enqueue_back(pp, s);
+    HIP_TRY(hipGetLastError());
+    s.busy = true;
+    s.timed = true;
+    return LC_OK;
+}
+
+int get_slot(lc_pipe *pipe, int slot, Slot **out) {
+    if (!pipe) return fail(LC_EINVAL, "null pipeline");
+    if (slot < 0 || slot >= (int)pipe->slots.size()) return fail(LC_EINVAL, "slot %d out of range", slot);
+    HIP_TRY(hipSetDevice(pipe->ctx->device));
+    *out = &pipe->slots[slot];
+    return LC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
+    int rc;
+    if (!out || !params) return fail(LC_EINVAL, "lc_pipe_create: null argument");
+    *out = nullptr;
+    if ((rc = ctx_bind(ctx))) return rc;
+    const lc_pipe_params &p = *params;
+    if (p.width <= 0 || p.height <= 0 || p.max_batch <= 0 || p.nslots <= 0) return fail(LC_EINVAL, "lc_pipe_create: bad sizes");
+    if (p.width > MAX_DIM || p.height > MAX_DIM) return fail(LC_EUNSUPPORTED, "frames above %d pixels a side are not supported", MAX_DIM);
+    if (p.color_code != LC_COLOR_BGR2GRAY && p.color_code != LC_COLOR_RGB2GRAY)
+        return fail(LC_EUNSUPPORTED, "color_code must be COLOR_BGR2GRAY (6) or COLOR_RGB2GRAY (7)");
+    if (!(p.canny_lo == p.canny_lo) || !(p.canny_hi == p.canny_hi)) return fail(LC_EINVAL, "NaN Canny threshold");
+    const bool hough = p.want_accumulator || p.want_segments;
+    if (p.want_segments && p.seg_capacity <= 0) return fail(LC_EINVAL, "seg_capacity must be positive");
+
+    lc_pipe *pp = new lc_pipe();
+    pp->ctx = ctx;
+    pp->p = p;
+    pp->p.roi_mask = pp->p.car_mask = nullptr;   // host pointers are not kept
+    pp->g = make_geo(p.width, p.height);
+    double t1 = std::min(p.canny_lo, p.canny_hi), t2 = std::max(p.canny_lo, p.canny_hi);
+    t1 = std::max(-1e9, std::min(1e9, t1));
+    t2 = std::max(-1e9, std::min(1e9, t2));
+    pp->low = (int)std::floor(t1);
+    pp->high = (int)std::floor(t2);
+    pp->line_length = (int)lrint(p.min_line_length);
+    pp->line_gap = (int)lrint(p.max_line_gap);
+
+    // ROI and car mask fold into one tile-major bit plane: keep = (roi == 255) && (car != 0)
+    if (p.roi_mask || p.car_mask) {
+        const Geo g = pp->g;
+        std::vector<uint64_t> bits(g.plane_words(), 0);
+        for (int y = 0; y < g.H; y++)
+            for (int x = 0; x < g.W; x++) {
+                size_t i = (size_t)y * g.W + x;
+                bool keep = true;
+                if (p.roi_mask) {
+                    uint8_t v = p.roi_mask[i];
+                    if (v != 0 && v != 255) {
+                        delete pp;
+                        return fail(LC_EUNSUPPORTED, "roi_mask must hold only 0 and 255 (found %d at %d,%d)", v, x, y);
+                    }
+                    keep = v != 0;
+                }
+                if (keep && p.car_mask) keep = p.car_mask[i] != 0;
+                if (keep) bits[((size_t)(y >> 6) * g.TX + (x >> 6)) * TILE + (y & 63)] |= 1ull << (x & 63);
+            }
+        if ((rc = pp->roi_bits.alloc(bits.size()))) { delete pp; return rc; }
+        hipError_t e = hipMemcpy(pp->roi_bits.p, bits.data(), bits.size() * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "roi upload failed: %s", hipGetErrorString(e)); }
+        pp->has_roi = true;
+    }
+
+    pp->slots.resize(p.nslots);
+    for (Slot &s : pp->slots) {
+        hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
+        if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+        for (auto &ev : s.ev) {
+            e = hipEventCreate(&ev);
+            if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
+        }
+        if ((rc = s.w.init_images(p.width, p.height, p.max_batch, true, p.keep_intermediates != 0, true))) { lc_pipe_destroy(pp); return rc; }
+        if (hough) {
+            // point list capacity per frame: an eighth of the pixels (a Canny map inside an ROI stays far below)
+            int cap = std::max(1024, (int)std::min<size_t>((size_t)p.width * p.height, (size_t)p.width * p.height / 8 + 1024));
+            if ((rc = s.w.init_points(cap))) { lc_pipe_destroy(pp); return rc; }
+            if ((rc = s.w.init_hough(p.rho, p.theta, std::max(p.seg_capacity, 1), p.want_accumulator != 0, p.want_segments != 0, s.st))) {
+                lc_pipe_destroy(pp);
+                return rc;
+            }
+        }
+        void *hp = nullptr;
+        if ((rc = lc_host_alloc_pinned(sizeof(int) * (HYST_CHUNK + 2), &hp))) { lc_pipe_destroy(pp); return rc; }
+        s.h_nact = (int *)hp;
+        if ((rc = lc_host_alloc_pinned(sizeof(int), &hp))) { lc_pipe_destroy(pp); return rc; }
+        s.h_status = (int *)hp;
+        *s.h_status = 0;
+        if ((rc = lc_host_alloc_pinned(sizeof(int) * p.max_batch, &hp))) { lc_pipe_destroy(pp); return rc; }
+        s.h_segcount = (int *)hp;
+        if ((rc = lc_host_alloc_pinned(sizeof(int32_t) * 4 * (size_t)p.max_batch * std::max(p.seg_capacity, 1), &hp))) { lc_pipe_destroy(pp); return rc; }
+        s.h_seg = (int32_t *)hp;
+    }
+    *out = pp;
+    return LC_OK;
+}
+
+int lc_pipe_destroy(lc_pipe *pipe) {
+    if (!pipe) return LC_OK;
+    (void)hipSetDevice(pipe->ctx->device);
+    for (Slot &s : pipe->slots) {
+        if (s.st) { (void)hipStreamSynchronize(s.st); }
+        for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
+        if (s.st) (void)hipStreamDestroy(s.st);
+        if (s.h_nact) (void)hipHostFree(s.h_nact);
+        if (s.h_status) (void)hipHostFree(s.h_status);
+        if (s.h_segcount) (void)hipHostFree(s.h_segcount);
+        if (s.h_seg) (void)hipHostFree(s.h_seg);
+    }
+    delete pipe;
+    return LC_OK;
+}
+
+int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "submit: bad frames argument");
+    if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
+    s->nframes = nframes;
+    s->input_bytes = (size_t)nframes * 3 * s->w.npix;
+    s->input = s->w.bgr.p;
+    HIP_TRY(hipEventRecord(s->ev[EV_START], s->st));
+    HIP_TRY(hipMemcpyAsync(s->w.bgr.p, host_bgr, s->input_bytes, hipMemcpyHostToDevice, s->st));
+    return enqueue_all(pipe, *s);
+}
+
+int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nframes) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!dev_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "submit: bad frames argument");
+    if (((uintptr_t)dev_bgr & 15) != 0) return fail(LC_EINVAL, "submit: device frames must be 16-byte aligned");
+    if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
+    s->nframes = nframes;
+    s->input_bytes = (size_t)nframes * 3 * s->w.npix;
+    s->input = (const uint8_t *)dev_bgr;
+    HIP_TRY(hipEventRecord(s->ev[EV_START], s->st));
+    return enqueue_all(pipe, *s);
+}
+
+int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
+    HIP_TRY(hipStreamSynchronize(s->st));
+    if (!chunk_converged(s->h_nact, HYST_CHUNK)) {
+        // rare: a weak chain crosses more tile borders than the rounds enqueued up front
+        for (;;) {
+            enqueue_hyst(s->w, s->nframes, s->rounds_done, HYST_CHUNK, s->st);
+            s->rounds_done += HYST_CHUNK;
+            HIP_TRY(hipMemcpyAsync(s->h_nact, s->w.nact.p, sizeof(int) * (HYST_CHUNK + 2), hipMemcpyDeviceToHost, s->st));
+            HIP_TRY(hipStreamSynchronize(s->st));
+            if (chunk_converged(s->h_nact, HYST_CHUNK)) break;
+        }
+        enqueue_back(pipe, *s);
+        HIP_TRY(hipStreamSynchronize(s->st));
+        s->timed = false;   // stage events no longer bracket the whole batch
+    }
+    s->busy = false;
+    const lc_pipe_params &p = pipe->p;
+    if (p.want_segments) {
+        if (*s->h_status) return fail(LC_ECAP, "HoughLinesP: a frame holds more edge points than the pipeline's point capacity (status %d)", *s->h_status);
+        if (seg_count) memcpy(seg_count, s->h_segcount, sizeof(int) * s->nframes);
+        if (seg_xyxy) memcpy(seg_xyxy, s->h_seg, sizeof(int32_t) * 4 * (size_t)s->nframes * s->w.seg_cap);
+    }
+    return LC_OK;
+}
+
+int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
+    if (!host_dst) return fail(LC_EINVAL, "null destination");
+    Work &w = s->w;
+    const void *src = nullptr;
+    size_t need = 0;
+    const size_t img = (size_t)s->nframes * w.npix;
+    switch (what) {
+        case LC_BUF_GRAY: src = w.inter ? w.gray.p : nullptr; need = img; break;
+        case LC_BUF_BLUR: src = (w.inter && pipe->p.blur) ? w.blur.p : nullptr; need = img; break;
+        case LC_BUF_EDGES: src = w.inter ? w.edges.p : nullptr; need = img; break;
+        case LC_BUF_MASKED: src = w.masked.p; need = img; break;
+        case LC_BUF_ACC: src = pipe->p.want_accumulator ? w.acc_full.p : nullptr;
+            need = sizeof(int32_t) * (size_t)s->nframes * w.hg.numangle * w.hg.numrho; break;
+        case LC_BUF_NPOINTS: src = (pipe->p.want_accumulator || pipe->p.want_segments) ? w.npoints.p : nullptr;
+            need = sizeof(int) * s->nframes; break;
+        default: return fail(LC_EINVAL, "unknown buffer id %d", what);
+    }
+    if (!src) return fail(LC_EINVAL, "buffer %d is not produced by this pipeline's configuration", what);
+    if (bytes < need) return fail(LC_ECAP, "destination holds %zu bytes, %zu needed", bytes, need);
+    HIP_TRY(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    return LC_OK;
+}
+
+int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!ms) return fail(LC_EINVAL, "null output");
+    if (s->busy || !s->timed) return fail(LC_EINVAL, "slot %d has no complete timing", slot);
+    int a, b;
+    switch (stage) {
+        case LC_STAGE_UPLOAD: a = EV_START; b = EV_UPLOADED; break;
+        case LC_STAGE_EDGE: a = EV_UPLOADED; b = EV_EDGE; break;
+        case LC_STAGE_POINTS: a = EV_EDGE; b = EV_POINTS; break;
+        case LC_STAGE_VOTE: a = EV_POINTS; b = EV_VOTE; break;
+        case LC_STAGE_LINES: a = EV_VOTE; b = EV_LINES; break;
+        case LC_STAGE_TOTAL: a = EV_START; b = EV_END; break;
+        default: return fail(LC_EINVAL, "unknown stage %d", stage);
+    }
+    HIP_TRY(hipEventElapsedTime(ms, s->ev[a], s->ev[b]));
+    return LC_OK;
+}
+
+int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!dev_ptr) return fail(LC_EINVAL, "null output");
+    *dev_ptr = s->w.bgr.p;
+    return LC_OK;
+}
+
+}  // extern "C"

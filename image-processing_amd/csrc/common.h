@@ -1,0 +1,72 @@
+// Internal declarations shared by the HIP translation units of liblanecv.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace lanecv {
+
+// ---- geometry of the bit-plane representation ------------------------------
+// The Canny classification and the final edge map live in HBM as bit planes,
+// one uint64 per 64 consecutive pixels of a row.
+//   tile-major plane  P[frame][ty][tx][row 0..63]   (64x64-pixel tiles; used by
+//                     the front kernel's stores and the hysteresis kernel's loads)
+//   row-major plane   M[frame][y][tx]               (used by point compaction and
+//                     the probabilistic Hough kernel)
+constexpr int TILE = 64;
+
+struct Geo {
+    int W, H;       // pixels
+    int TX, TY;     // tiles: ceil(W/64), ceil(H/64)
+    __host__ __device__ size_t plane_words() const { return (size_t)TX * TY * TILE; }   // per frame, tile-major
+    __host__ __device__ size_t rowplane_words() const { return (size_t)TX * H; }        // per frame, row-major
+};
+
+inline Geo make_geo(int W, int H) {
+    Geo g; g.W = W; g.H = H; g.TX = (W + TILE - 1) / TILE; g.TY = (H + TILE - 1) / TILE; return g;
+}
+
+// Per-angle constants of HoughLinesProbabilistic, computed on the host exactly
+// as OpenCV's CPU code does (double cos/sin scaled by the float 1/rho, narrowed
+// to float; the walk step uses float division) and uploaded once.
+struct AngleEntry {
+    float c, s;      // trigtab[2n], trigtab[2n+1]
+    int xflag;       // 1: x is the walk's major axis
+    int dmaj;        // +-1 step of the major axis
+    int dmin;        // 16.16 step of the minor axis
+    int pad;
+};
+
+// ---- launchers (each enqueues on `st`; no synchronisation inside) ----------
+// edge stage
+void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_t *gray, hipStream_t st);
+void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st);
+// in_kind: 0 = gray bytes in, 1 = interleaved 3-channel bytes in
+void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes,
+                  int low, int high, uint64_t *planeS, uint64_t *planeW,
+                  uint8_t *gray_out, uint8_t *blur_out, hipStream_t st);
+void launch_hyst_round(Geo g, int nframes, int round, uint64_t *planeS, const uint64_t *planeW,
+                       int *act, int *nact, hipStream_t st);
+// roi_bits: tile-major plane shared by all frames, or nullptr
+void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits,
+                     uint8_t *edges_out, uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st);
+void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t *dst, size_t n, hipStream_t st);
+void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowplane, int *rowcount, hipStream_t st);
+// points + Hough
+void launch_rowscan(Geo g, int nframes, const int *rowcount, int *rowoff, int *npoints, hipStream_t st);
+void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, const int *rowoff, uint32_t *nz, int nz_cap, hipStream_t st);
+void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints,
+                 const AngleEntry *tab, int numangle, int numrho, int32_t *acc, hipStream_t st);
+void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
+                 const AngleEntry *tab, int numangle, int numrho, int32_t *acc,
+                 int threshold, int line_length, int line_gap,
+                 int32_t *seg, int seg_cap, int *seg_count, int *status, hipStream_t st);
+// polygons
+struct PolyEdgeDev { int y0, y1; long long x, dx; };
+struct LineDev { int x0, y0, count, vert, dmaj, dmin, dmajor_len, dminor_len; };
+void launch_fill_spans(uint8_t *img, int W, int H, const PolyEdgeDev *edges, int nedges, int ymin, int ymax,
+                       int color, hipStream_t st);
+void launch_draw_lines(uint8_t *img, int W, int H, const LineDev *lines, int nlines, int color, hipStream_t st);
+void launch_fill_rect(uint8_t *img, int W, int H, int x1, int y1, int x2, int y2, int color, hipStream_t st);
+
+}  // namespace lanecv

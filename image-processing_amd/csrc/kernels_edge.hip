@@ -1,0 +1,506 @@
+// Edge stage of the lane pipeline for gfx950: gray conversion, 5x5 binomial
+// blur, Sobel, non-maximum suppression, hysteresis and the ROI mask.
+//
+// Arithmetic contract (bit-exact with OpenCV's 8U fixed-point paths):
+//   gray   (b*k0 + g*k1 + r*k2 + 2^14) >> 15, weights 3735/19235/9798
+//   blur   [1 4 6 4 1]^2, BORDER_REFLECT_101, (S + 128) >> 8 computed as
+//          hline << 4 (16 bit) then (vline + 2^11) >> 12
+//   Sobel  3x3, BORDER_REPLICATE; magnitude |dx| + |dy|, zero outside the image
+//   NMS    three sectors split at tan(22.5 deg) = 13573 / 2^15 with OpenCV's
+//          asymmetric > / >= comparisons; strict thresholds
+//   hysteresis: 8-connected closure from strong through weak pixels
+#include "common.h"
+
+namespace lanecv {
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        p = p < 0 ? -p : 2 * (len - 1) - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+__device__ __forceinline__ int clampi(int p, int len) { return p < 0 ? 0 : (p >= len ? len - 1 : p); }
+
+// ---------------------------------------------------------------------------
+// stand-alone gray conversion (cvtColor drop-in): 4 pixels per thread
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gray(const uint8_t *__restrict__ src, size_t npix, int k0, int k1, int k2,
+                                              uint8_t *__restrict__ dst) {
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 pixels = 12 source bytes
+    size_t p0 = q * 4;
+    if (p0 >= npix) return;
+    if (p0 + 4 <= npix) {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(src) + q * 3;
+        uint32_t a = s[0], b = s[1], c = s[2];
+        uint32_t g0 = ((a & 255) * k0 + ((a >> 8) & 255) * k1 + ((a >> 16) & 255) * k2 + (1 << 14)) >> 15;
+        uint32_t g1 = ((a >> 24) * k0 + (b & 255) * k1 + ((b >> 8) & 255) * k2 + (1 << 14)) >> 15;
+        uint32_t g2 = (((b >> 16) & 255) * k0 + (b >> 24) * k1 + (c & 255) * k2 + (1 << 14)) >> 15;
+        uint32_t g3 = (((c >> 8) & 255) * k0 + ((c >> 16) & 255) * k1 + (c >> 24) * k2 + (1 << 14)) >> 15;
+        reinterpret_cast<uint32_t *>(dst)[q] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    } else {
+        for (size_t p = p0; p < npix; p++)
+            dst[p] = (uint8_t)((src[3 * p] * k0 + src[3 * p + 1] * k1 + src[3 * p + 2] * k2 + (1 << 14)) >> 15);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stand-alone 5x5 blur (GaussianBlur drop-in): one 64x16 tile per block
+// ---------------------------------------------------------------------------
+constexpr int BT_W = 64, BT_H = 16;
+__global__ __launch_bounds__(256) void k_blur5(const uint8_t *__restrict__ src, int W, int H, uint8_t *__restrict__ dst) {
+    __shared__ uint8_t sg[BT_H + 4][BT_W + 4];
+    __shared__ uint16_t sh[BT_H + 4][BT_W];
+    const int tx0 = blockIdx.x * BT_W, ty0 = blockIdx.y * BT_H;
+    const size_t fo = (size_t)blockIdx.z * W * H;
+    for (int i = threadIdx.x; i < (BT_H + 4) * (BT_W + 4); i += 256) {
+        int r = i / (BT_W + 4), c = i % (BT_W + 4);
+        int y = reflect101(ty0 - 2 + r, H), x = reflect101(tx0 - 2 + c, W);
+        sg[r][c] = src[fo + (size_t)y * W + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (BT_H + 4) * BT_W; i += 256) {
+        int r = i / BT_W, c = i % BT_W;
+        int v = sg[r][c] + sg[r][c + 4] + 4 * (sg[r][c + 1] + sg[r][c + 3]) + 6 * sg[r][c + 2];
+        sh[r][c] = (uint16_t)(v << 4);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BT_H * BT_W; i += 256) {
+        int r = i / BT_W, c = i % BT_W;
+        int y = ty0 + r, x = tx0 + c;
+        if (y < H && x < W) {
+            uint32_t v = (uint32_t)sh[r][c] + sh[r + 4][c] + 4u * ((uint32_t)sh[r + 1][c] + sh[r + 3][c]) + 6u * sh[r + 2][c];
+            dst[fo + (size_t)y * W + x] = (uint8_t)((v + (1u << 11)) >> 12);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused front kernel: (BGR ->) gray (-> blur) -> Sobel -> NMS -> class bit planes
+// One block = one 64 x FT_H output tile; every stage is staged through LDS with
+// the halo the later stages need (blur 2 + Sobel 1 + NMS 1 = 4 pixels).
+// Only in-image coordinates are computed; reads that leave the image are
+// remapped with the border rule of the stage that reads.
+// ---------------------------------------------------------------------------
+constexpr int FT_W = 64, FT_H = 32, FNT = 256;
+
+template <bool IN_BGR, bool BLUR>
+__global__ __launch_bounds__(FNT) void k_front(const uint8_t *__restrict__ src, size_t src_bytes, Geo g, int k0, int k1,
+                                               int k2, int low, int high, uint64_t *__restrict__ planeS,
+                                               uint64_t *__restrict__ planeW, uint8_t *__restrict__ gray_out,
+                                               uint8_t *__restrict__ blur_out) {
+    constexpr int HALO = BLUR ? 4 : 2;
+    constexpr int GW = FT_W + 2 * HALO, GH = FT_H + 2 * HALO;   // gray region
+    constexpr int SW = FT_W + 4, SH = FT_H + 4;                 // Sobel-input region (halo 2)
+    constexpr int MW = FT_W + 2, MH = FT_H + 2;                 // magnitude region (halo 1)
+    constexpr int RAWW = IN_BGR ? (3 * GW + 6) / 4 + 1 : 1;     // staging words per row
+
+    __shared__ uint32_t sraw[IN_BGR ? GH : 1][RAWW];
+    __shared__ uint8_t sg[GH][GW];
+    __shared__ uint16_t sh[BLUR ? GH : 1][BLUR ? SW : 1];
+    __shared__ uint8_t sblur[BLUR ? SH : 1][BLUR ? SW : 1];
+    __shared__ uint16_t smag[MH][MW];
+    __shared__ uint8_t sdir[MH][MW];
+
+    const int W = g.W, H = g.H;
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * FT_W, ty0 = blockIdx.y * FT_H, f = blockIdx.z;
+    const int gx0 = tx0 - HALO, gy0 = ty0 - HALO;
+    const size_t plane_base = ((size_t)(f * g.TY + (ty0 >> 6)) * g.TX + blockIdx.x) * TILE + (ty0 & 63);
+
+    if (ty0 >= H) {   // tile rows that only exist to pad the plane to whole 64-row tiles
+        if (tid < FT_H) { planeS[plane_base + tid] = 0; planeW[plane_base + tid] = 0; }
+        return;
+    }
+
+    // ---- 1. gray into LDS -------------------------------------------------
+    const int cx0 = gx0 < 0 ? 0 : gx0;                       // first in-image column of the region
+    const int cx1 = (gx0 + GW < W) ? gx0 + GW : W;           // one past the last
+    if constexpr (IN_BGR) {
+        const size_t fbase = (size_t)f * 3 * W * H;
+        for (int i = tid; i < GH * RAWW; i += FNT) {
+            int r = i / RAWW, k = i % RAWW;
+            int y = gy0 + r;
+            if ((unsigned)y >= (unsigned)H) continue;
+            size_t a0 = fbase + (size_t)y * 3 * W + 3 * (size_t)cx0;
+            size_t aw = (a0 & ~(size_t)3) + 4 * (size_t)k;
+            size_t aend = a0 + 3 * (size_t)(cx1 - cx0);
+            if (aw >= aend) continue;
+            uint32_t v;
+            if (aw + 4 <= src_bytes) v = *reinterpret_cast<const uint32_t *>(src + aw);
+            else {
+                v = 0;
+                for (int b = 0; b < 4 && aw + b < src_bytes; b++) v |= (uint32_t)src[aw + b] << (8 * b);
+            }
+            sraw[r][k] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < GH * GW; i += FNT) {
+            int r = i / GW, c = i % GW;
+            int y = gy0 + r, x = gx0 + c;
+            if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) continue;
+            size_t a0 = fbase + (size_t)y * 3 * W + 3 * (size_t)cx0;
+            int bo = (int)(a0 & 3) + 3 * (x - cx0);
+            const uint8_t *rb = reinterpret_cast<const uint8_t *>(&sraw[r][0]);
+            sg[r][c] = (uint8_t)((rb[bo] * k0 + rb[bo + 1] * k1 + rb[bo + 2] * k2 + (1 << 14)) >> 15);
+        }
+    } else {
+        const size_t fbase = (size_t)f * W * H;
+        for (int i = tid; i < GH * GW; i += FNT) {
+            int r = i / GW, c = i % GW;
+            int y = gy0 + r, x = gx0 + c;
+            if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) continue;
+            sg[r][c] = src[fbase + (size_t)y * W + x];
+        }
+    }
+    __syncthreads();
+    if (IN_BGR && gray_out) {
+        for (int i = tid; i < FT_H * FT_W; i += FNT) {
+            int r = i / FT_W, c = i % FT_W;
+            int y = ty0 + r, x = tx0 + c;
+            if (y < H && x < W) gray_out[(size_t)f * W * H + (size_t)y * W + x] = sg[r + HALO][c + HALO];
+        }
+    }
+
+    // ---- 2. optional 5x5 blur ----------------------------------------------
+    if constexpr (BLUR) {
+        for (int i = tid; i < GH * SW; i += FNT) {
+            int r = i / SW, c = i % SW;
+            int y = gy0 + r, x = tx0 - 2 + c;
+            if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) continue;
+            int a = sg[r][reflect101(x - 2, W) - gx0], b = sg[r][reflect101(x - 1, W) - gx0];
+            int cc = sg[r][x - gx0];
+            int d = sg[r][reflect101(x + 1, W) - gx0], e = sg[r][reflect101(x + 2, W) - gx0];
+            sh[r][c] = (uint16_t)((a + e + 4 * (b + d) + 6 * cc) << 4);
+        }
+        __syncthreads();
+        for (int i = tid; i < SH * SW; i += FNT) {
+            int r = i / SW, c = i % SW;
+            int y = ty0 - 2 + r, x = tx0 - 2 + c;
+            if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) continue;
+            uint32_t v0 = sh[reflect101(y - 2, H) - gy0][c], v1 = sh[reflect101(y - 1, H) - gy0][c];
+            uint32_t v2 = sh[y - gy0][c];
+            uint32_t v3 = sh[reflect101(y + 1, H) - gy0][c], v4 = sh[reflect101(y + 2, H) - gy0][c];
+            uint8_t o = (uint8_t)((v0 + v4 + 4u * (v1 + v3) + 6u * v2 + (1u << 11)) >> 12);
+            sblur[r][c] = o;
+            if (blur_out && r >= 2 && r < SH - 2 && c >= 2 && c < SW - 2)
+                blur_out[(size_t)f * W * H + (size_t)y * W + x] = o;
+        }
+        __syncthreads();
+    }
+
+    // ---- 3. Sobel + magnitude + direction sector ---------------------------
+    for (int i = tid; i < MH * MW; i += FNT) {
+        int r = i / MW, c = i % MW;
+        int y = ty0 - 1 + r, x = tx0 - 1 + c;
+        uint16_t m = 0;
+        uint8_t dir = 0;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            // Sobel-input region starts at (ty0-2, tx0-2)
+            int ym = clampi(y - 1, H) - (ty0 - 2), y0 = y - (ty0 - 2), yp = clampi(y + 1, H) - (ty0 - 2);
+            int xm = clampi(x - 1, W) - (tx0 - 2), x0 = x - (tx0 - 2), xp = clampi(x + 1, W) - (tx0 - 2);
+            int p00, p01, p02, p10, p12, p20, p21, p22;
+            if constexpr (BLUR) {
+                p00 = sblur[ym][xm]; p01 = sblur[ym][x0]; p02 = sblur[ym][xp];
+                p10 = sblur[y0][xm];                      p12 = sblur[y0][xp];
+                p20 = sblur[yp][xm]; p21 = sblur[yp][x0]; p22 = sblur[yp][xp];
+            } else {
+                p00 = sg[ym][xm]; p01 = sg[ym][x0]; p02 = sg[ym][xp];
+                p10 = sg[y0][xm];                   p12 = sg[y0][xp];
+                p20 = sg[yp][xm]; p21 = sg[yp][x0]; p22 = sg[yp][xp];
+            }
+            int dx = (p02 + 2 * p12 + p22) - (p00 + 2 * p10 + p20);
+            int dy = (p20 + 2 * p21 + p22) - (p00 + 2 * p01 + p02);
+            int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+            m = (uint16_t)(ax + ay);
+            int ys = ay << 15, tg22x = ax * 13573;
+            if (ys < tg22x) dir = 0;
+            else if (ys > tg22x + (ax << 16)) dir = 1;
+            else dir = ((dx ^ dy) < 0) ? 3 : 2;
+        }
+        smag[r][c] = m;
+        sdir[r][c] = dir;
+    }
+    __syncthreads();
+
+    // ---- 4. non-maximum suppression + double threshold -> bit planes --------
+    for (int i = tid; i < FT_H * FT_W; i += FNT) {
+        int r = i / FT_W, c = i % FT_W;   // r is uniform across the wavefront, c = lane
+        int y = ty0 + r, x = tx0 + c;
+        bool strong = false, weak = false;
+        if (y < H && x < W) {
+            int m = smag[r + 1][c + 1];
+            if (m > low) {
+                bool keep;
+                switch (sdir[r + 1][c + 1]) {
+                    case 0: keep = m > smag[r + 1][c] && m >= smag[r + 1][c + 2]; break;
+                    case 1: keep = m > smag[r][c + 1] && m >= smag[r + 2][c + 1]; break;
+                    case 2: keep = m > smag[r][c] && m > smag[r + 2][c + 2]; break;
+                    default: keep = m > smag[r][c + 2] && m > smag[r + 2][c]; break;
+                }
+                strong = keep && m > high;
+                weak = keep && !strong;
+            }
+        }
+        uint64_t bs = __ballot(strong), bw = __ballot(weak);
+        if (c == 0) { planeS[plane_base + r] = bs; planeW[plane_base + r] = bw; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// hysteresis: one wavefront owns one 64x64 tile as 2 x 64 bit rows in registers
+// (lane = row).  A round floods strong bits through weak bits inside the tile,
+// seeded by the strong pixels of the one-pixel ring around it; tiles whose
+// border gained a strong pixel wake the neighbours that touch it for the next
+// round.  Rounds repeat (host side) until no tile is woken.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t flood_row(uint64_t seed, uint64_t cand) {
+    // every run of 1s in cand that holds a seed bit becomes all seed
+    seed &= cand;
+    uint64_t up = seed | (cand & ~(cand + seed));              // towards bit 63
+    uint64_t cr = __brevll(cand), sr = __brevll(up);
+    uint64_t dn = sr | (cr & ~(cr + sr));                      // towards bit 0
+    return __brevll(dn);
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+constexpr int HY_WAVES = 4;
+__global__ __launch_bounds__(64 * HY_WAVES) void k_hyst(Geo g, int ntiles_total, int round, uint64_t *__restrict__ planeS,
+                                                       const uint64_t *__restrict__ planeW, int *__restrict__ act,
+                                                       int *__restrict__ nact) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * HY_WAVES + (threadIdx.x >> 6);   // global tile index over all frames
+    if (t >= ntiles_total) return;
+    if (round > 0 && act[t] != round) return;
+    const int tiles_per_frame = g.TX * g.TY;
+    const int f = t / tiles_per_frame, tt = t % tiles_per_frame;
+    const int ty = tt / g.TX, tx = tt % g.TX;
+    const size_t base = (size_t)t * TILE;
+    uint64_t Wk = planeW[base + lane];
+    if (__ballot(Wk != 0) == 0) return;
+    uint64_t S = planeS[base + lane];
+    Wk &= ~S;
+    const uint64_t S_in = S;
+    const uint64_t cand = S | Wk;
+
+    // strong bits of the ring around the tile
+    const bool hasL = tx > 0, hasR = tx + 1 < g.TX, hasT = ty > 0, hasB = ty + 1 < g.TY;
+    const size_t fb = (size_t)f * tiles_per_frame;
+    uint64_t Lw = hasL ? planeS[(fb + (size_t)ty * g.TX + tx - 1) * TILE + lane] : 0;
+    uint64_t Rw = hasR ? planeS[(fb + (size_t)ty * g.TX + tx + 1) * TILE + lane] : 0;
+    uint64_t lcol = Lw >> 63, rcol = Rw & 1;     // (row, -1) and (row, 64)
+    // lanes 0..2: row 63 of tiles (ty-1, tx-1..tx+1); lanes 3..5: row 0 of tiles (ty+1, tx-1..tx+1)
+    uint64_t edge = 0;
+    if (lane < 6) {
+        int dy = lane < 3 ? -1 : 1, dx = (lane % 3) - 1;
+        int yy = ty + dy, xx = tx + dx;
+        if (yy >= 0 && yy < g.TY && xx >= 0 && xx < g.TX)
+            edge = planeS[(fb + (size_t)yy * g.TX + xx) * TILE + (dy < 0 ? 63 : 0)];
+    }
+    (void)hasT; (void)hasB;
+    uint64_t tl = shfl_u64(edge, 0) >> 63, tm = shfl_u64(edge, 1), tr = shfl_u64(edge, 2) & 1;
+    uint64_t bl = shfl_u64(edge, 3) >> 63, bm = shfl_u64(edge, 4), br = shfl_u64(edge, 5) & 1;
+    // column neighbours of row r: rows r-1, r, r+1 of the left / right ring
+    uint64_t l_up = shfl_u64(lcol, lane - 1), l_dn = shfl_u64(lcol, lane + 1);
+    uint64_t r_up = shfl_u64(rcol, lane - 1), r_dn = shfl_u64(rcol, lane + 1);
+    if (lane == 0) { l_up = tl; r_up = tr; }
+    if (lane == 63) { l_dn = bl; r_dn = br; }
+    uint64_t seed = ((lcol | l_up | l_dn) & 1) | (((rcol | r_up | r_dn) & 1) << 63);
+    if (lane == 0) seed |= tm | (tm << 1) | (tm >> 1) | tl | (tr << 63);
+    if (lane == 63) seed |= bm | (bm << 1) | (bm >> 1) | bl | (br << 63);
+    S |= Wk & seed;
+
+    for (;;) {
+        uint64_t Sf = flood_row(S, cand);
+        uint64_t up = shfl_u64(Sf, lane - 1), dn = shfl_u64(Sf, lane + 1);
+        if (lane == 0) up = 0;
+        if (lane == 63) dn = 0;
+        uint64_t v = up | dn;
+        uint64_t Sn = Sf | (cand & (v | (v << 1) | (v >> 1)));
+        bool ch = Sn != S;
+        S = Sn;
+        if (__ballot(ch) == 0) break;
+    }
+
+    const uint64_t added = S & ~S_in;
+    const uint64_t any = __ballot(added != 0);
+    if (any == 0) return;
+    if (added) planeS[base + lane] = S;
+    // wake the neighbours that touch a newly strong border pixel
+    const bool top = (any & 1) != 0, bot = (any >> 63) != 0;
+    const bool left = __ballot((added & 1) != 0) != 0, right = __ballot((added >> 63) != 0) != 0;
+    const uint64_t a0 = shfl_u64(added, 0), a63 = shfl_u64(added, 63);
+    if (lane < 8) {
+        // neighbour order: 0 T, 1 B, 2 L, 3 R, 4 TL, 5 TR, 6 BL, 7 BR
+        const int dys[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
+        const int dxs[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+        bool want;
+        switch (lane) {
+            case 0: want = top; break;
+            case 1: want = bot; break;
+            case 2: want = left; break;
+            case 3: want = right; break;
+            case 4: want = top && (a0 & 1); break;
+            case 5: want = top && (a0 >> 63); break;
+            case 6: want = bot && (a63 & 1); break;
+            default: want = bot && (a63 >> 63); break;
+        }
+        int yy = ty + dys[lane], xx = tx + dxs[lane];
+        if (want && yy >= 0 && yy < g.TY && xx >= 0 && xx < g.TX) {
+            act[fb + (size_t)yy * g.TX + xx] = round + 1;
+            atomicAdd(&nact[round + 1], 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// finalize: strong plane (& ROI bits) -> 0/255 bytes, row-major bit plane for the
+// Hough stage, per-row point counts.  One wavefront per 64x64 tile; a lane
+// expands 16 pixels at a time so that stores are 16 bytes wide.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand4(uint32_t bits4) {
+    // 4 bits -> 4 bytes of 0x00 / 0xFF
+    uint32_t r = (bits4 * 0x00204081u) & 0x01010101u;
+    return r * 255u;
+}
+
+__global__ __launch_bounds__(256) void k_finalize(Geo g, int ntiles_total, const uint64_t *__restrict__ planeS,
+                                                  const uint64_t *__restrict__ roi_bits, uint8_t *__restrict__ edges_out,
+                                                  uint8_t *__restrict__ masked_out, uint64_t *__restrict__ rowplane,
+                                                  int *__restrict__ rowcount) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles_total) return;
+    const int tiles_per_frame = g.TX * g.TY;
+    const int f = t / tiles_per_frame, tt = t % tiles_per_frame;
+    const int ty = tt / g.TX, tx = tt % g.TX;
+    const int W = g.W, H = g.H;
+    // lane = row: masked bits, row-major plane and row counts
+    uint64_t S = planeS[(size_t)t * TILE + lane];
+    uint64_t M = roi_bits ? (S & roi_bits[(size_t)tt * TILE + lane]) : S;
+    const int yrow = ty * TILE + lane;
+    if (yrow < H) {
+        if (rowplane) rowplane[((size_t)f * H + yrow) * g.TX + tx] = M;
+        if (rowcount) {
+            int c = __popcll(M);
+            if (c) atomicAdd(&rowcount[(size_t)f * H + yrow], c);
+        }
+    }
+    // byte expansion: iteration k covers rows 4k..4k+3, lane covers 16 pixels
+    const bool vec_ok = (W % 16) == 0;
+    const int sub = lane & 3, rsel = lane >> 2;   // 16-pixel column group, row within the group of 16 rows
+    for (int k = 0; k < 4; k++) {
+        int r = k * 16 + rsel;
+        uint64_t Sr = shfl_u64(S, r), Mr = shfl_u64(M, r);
+        int y = ty * TILE + r, x = tx * TILE + sub * 16;
+        if (y >= H || x >= W) continue;
+        uint32_t sb = (uint32_t)(Sr >> (sub * 16)) & 0xFFFFu, mb = (uint32_t)(Mr >> (sub * 16)) & 0xFFFFu;
+        size_t o = (size_t)f * W * H + (size_t)y * W + x;
+        uint4 es, ms;
+        es.x = expand4(sb & 15); es.y = expand4((sb >> 4) & 15); es.z = expand4((sb >> 8) & 15); es.w = expand4(sb >> 12);
+        ms.x = expand4(mb & 15); ms.y = expand4((mb >> 4) & 15); ms.z = expand4((mb >> 8) & 15); ms.w = expand4(mb >> 12);
+        if (vec_ok) {
+            if (edges_out) *reinterpret_cast<uint4 *>(edges_out + o) = es;
+            if (masked_out) *reinterpret_cast<uint4 *>(masked_out + o) = ms;
+        } else {
+            int n = W - x < 16 ? W - x : 16;
+            for (int j = 0; j < n; j++) {
+                if (edges_out) edges_out[o + j] = (sb >> j) & 1 ? 255 : 0;
+                if (masked_out) masked_out[o + j] = (mb >> j) & 1 ? 255 : 0;
+            }
+        }
+    }
+}
+
+// bitwise_and with an optional mask (dst = 0 where mask == 0)
+__global__ __launch_bounds__(256) void k_and(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                             const uint8_t *__restrict__ mask, uint8_t *__restrict__ dst, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        uint32_t va = *reinterpret_cast<const uint32_t *>(a + i), vb = *reinterpret_cast<const uint32_t *>(b + i);
+        uint32_t v = va & vb;
+        if (mask) {
+            uint32_t m = *reinterpret_cast<const uint32_t *>(mask + i);
+            // per byte: 0xFF where the mask byte is non-zero
+            uint32_t nzb = ((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu | m) & 0x80808080u;
+            v &= (nzb >> 7) * 255u;
+        }
+        *reinterpret_cast<uint32_t *>(dst + i) = v;
+    } else {
+        for (; i < n; i++) dst[i] = (mask && !mask[i]) ? 0 : (a[i] & b[i]);
+    }
+}
+
+// non-zero bytes -> row-major bit plane + row counts (front end of the stand-alone Hough calls)
+__global__ __launch_bounds__(256) void k_pack_nonzero(const uint8_t *__restrict__ img, Geo g, int nframes,
+                                                      uint64_t *__restrict__ rowplane, int *__restrict__ rowcount) {
+    // one wavefront per (frame, row); lane l tests pixels l, 64+l, ...
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)nframes * g.H) return;
+    const uint8_t *p = img + (size_t)row * g.W;
+    int cnt = 0;
+    for (int tx = 0; tx < g.TX; tx++) {
+        int x = tx * 64 + lane;
+        uint64_t b = __ballot(x < g.W && p[x] != 0);
+        if (lane == 0) rowplane[(size_t)row * g.TX + tx] = b;
+        cnt += __popcll(b);
+    }
+    if (lane == 0) rowcount[row] = cnt;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_t *gray, hipStream_t st) {
+    size_t npix = (size_t)W * H * nframes;
+    int k0 = code == 6 ? 3735 : 9798, k2 = code == 6 ? 9798 : 3735;
+    size_t groups = (npix + 3) / 4;
+    hipLaunchKernelGGL(k_gray, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, bgr, npix, k0, 19235, k2, gray);
+}
+
+void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st) {
+    dim3 grid((W + BT_W - 1) / BT_W, (H + BT_H - 1) / BT_H, nframes);
+    hipLaunchKernelGGL(k_blur5, grid, dim3(256), 0, st, src, W, H, dst);
+}
+
+void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes, int low,
+                  int high, uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, hipStream_t st) {
+    int k0 = code == 6 ? 3735 : 9798, k2 = code == 6 ? 9798 : 3735;
+    dim3 grid(g.TX, g.TY * (TILE / FT_H), nframes), block(FNT);
+#define LC_FRONT(B, L) hipLaunchKernelGGL((k_front<B, L>), grid, block, 0, st, src, src_bytes, g, k0, 19235, k2, low, high, planeS, planeW, gray_out, blur_out)
+    if (in_kind == 1) { if (blur) LC_FRONT(true, true); else LC_FRONT(true, false); }
+    else { if (blur) LC_FRONT(false, true); else LC_FRONT(false, false); }
+#undef LC_FRONT
+}
+
+void launch_hyst_round(Geo g, int nframes, int round, uint64_t *planeS, const uint64_t *planeW, int *act, int *nact,
+                       hipStream_t st) {
+    int nt = g.TX * g.TY * nframes;
+    hipLaunchKernelGGL(k_hyst, dim3((nt + HY_WAVES - 1) / HY_WAVES), dim3(64 * HY_WAVES), 0, st, g, nt, round, planeS, planeW,
+                       act, nact);
+}
+
+void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,
+                     uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st) {
+    int nt = g.TX * g.TY * nframes;
+    hipLaunchKernelGGL(k_finalize, dim3((nt + 3) / 4), dim3(256), 0, st, g, nt, planeS, roi_bits, edges_out, masked_out,
+                       rowplane, rowcount);
+}
+
+void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t *dst, size_t n, hipStream_t st) {
+    size_t groups = (n + 3) / 4;
+    hipLaunchKernelGGL(k_and, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, a, b, mask, dst, n);
+}
+
+void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowplane, int *rowcount, hipStream_t st) {
+    long long rows = (long long)nframes * g.H;
+    hipLaunchKernelGGL(k_pack_nonzero, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, img, g, nframes, rowplane, rowcount);
+}
+
+}  // namespace lanecv

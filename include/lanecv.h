@@ -1,0 +1,169 @@
+/*
+ * lanecv.h -- C ABI of the MI355X lane-pipeline library (liblanecv.so).
+ *
+ * Every entry point replaces one call the reference's lane scripts make into
+ * the third-party cv2 module; the citation beside each declaration names the
+ * reference call site (file:line under the reference repository).  Plain C:
+ * pointers and sizes only, no exceptions cross this boundary.  Every function
+ * returns LC_OK (0) or a negative LC_E* code; lc_last_error() returns the
+ * message of the calling thread's last failure.
+ *
+ * Images are row-major uint8.  Colour frames are H x W x 3 interleaved in
+ * memory order (what cv2.imread / VideoCapture.read return); gray images,
+ * edge maps and masks are H x W.  A stride is the distance between rows in
+ * bytes.  All per-op functions take HOST pointers and are synchronous; the
+ * lc_pipe_* functions are the batched, asynchronous, device-resident path.
+ */
+#ifndef LANECV_H
+#define LANECV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_OK            0
+#define LC_EINVAL       -1   /* bad argument (cv2 would raise cv2.error) */
+#define LC_ENOMEM       -2
+#define LC_ECAP         -3   /* caller-provided output capacity too small */
+#define LC_EHIP         -4   /* HIP runtime failure (message has the HIP error) */
+#define LC_EUNSUPPORTED -5   /* valid cv2 call outside the supported parameter domain */
+
+/* cv2.COLOR_BGR2GRAY / cv2.COLOR_RGB2GRAY */
+#define LC_COLOR_BGR2GRAY 6
+#define LC_COLOR_RGB2GRAY 7
+
+typedef struct lc_ctx lc_ctx;     /* bound to one HIP device; calls on one ctx are serialised by the caller */
+typedef struct lc_pipe lc_pipe;   /* a configured batched pipeline living on a ctx */
+
+int lc_version(void);
+const char *lc_last_error(void);
+
+/* One context per GPU / worker thread.  Fails (LC_EHIP) when no HIP device is usable. */
+int lc_create(int device, lc_ctx **out);
+int lc_destroy(lc_ctx *ctx);
+
+/* Pinned host memory for frame rings fed to lc_pipe_submit_host. */
+int lc_host_alloc_pinned(size_t bytes, void **out);
+int lc_host_free(void *p);
+
+/* ---- per-op entry points (host pointers, synchronous) -------------------- */
+
+/* cv2.cvtColor(src, COLOR_BGR2GRAY | COLOR_RGB2GRAY), 8UC3 -> 8UC1.
+ * Replaces: Simple Lane Detection with OpenCV_2(images).py:69 (RGB2GRAY),
+ *           F1_vo_Lane_Tracking.py:186 (BGR2GRAY). */
+int lc_cvt_gray(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
+                int code, uint8_t *dst, size_t dst_stride);
+
+/* cv2.GaussianBlur(src, (5,5), 0), 8UC1, BORDER_REFLECT_101.
+ * Replaces: F1_vo_Lane_Tracking.py:97. */
+int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
+                 uint8_t *dst, size_t dst_stride);
+
+/* cv2.Canny(image, threshold1, threshold2) with apertureSize 3, L2gradient False.
+ * Replaces: Simple Lane Detection with OpenCV_2(images).py:72 (100, 200),
+ *           F1_vo_Lane_Tracking.py:98 (50, 150). */
+int lc_canny(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
+             double threshold1, double threshold2, uint8_t *dst, size_t dst_stride);
+
+/* cv2.fillPoly(img, pts, color) with LINE_8, shift 0, on an 8UC1 image, in place.
+ * pts holds the (x, y) int32 pairs of all contours back to back, npts[i] vertices each.
+ * Replaces: Simple Lane Detection with OpenCV_2(images).py:20,
+ *           F1_vo_Lane_Tracking.py:111, :175. */
+int lc_fill_poly(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride,
+                 const int32_t *pts, const int *npts, int ncontours, int color);
+
+/* cv2.rectangle(img, pt1, pt2, color, -1) (filled) on an 8UC1 image, in place.
+ * Replaces: F1_vo_Lane_Tracking.py:179-180. */
+int lc_rectangle_filled(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride,
+                        int x1, int y1, int x2, int y2, int color);
+
+/* cv2.bitwise_and(a, b[, mask=mask]) on 8UC1 images; mask may be NULL.
+ * Replaces: Simple Lane Detection with OpenCV_2(images).py:23,
+ *           F1_vo_Lane_Tracking.py:102 (mask=), :112. */
+int lc_and(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size_t b_stride,
+           const uint8_t *mask, size_t mask_stride, uint8_t *dst, size_t dst_stride, int w, int h);
+
+/* Geometry HoughLinesP derives from (w, h, rho, theta): number of angles and of
+ * rho bins.  Either output may be NULL. */
+int lc_hough_geometry(int w, int h, double rho, double theta, int *numangle, int *numrho);
+
+/* Full-vote Hough accumulator of an 8UC1 edge map: every non-zero pixel adds one
+ * vote per angle at the bin HoughLinesP would use; acc is [numangle][numrho] int32.
+ * (cv2.HoughLinesP never exposes its accumulator; this is the object the
+ * accumulator parity test compares.) */
+int lc_hough_accum(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride,
+                   double rho, double theta, int32_t *acc, int acc_capacity,
+                   int *numangle, int *numrho);
+
+/* cv2.HoughLinesP(image, rho, theta, threshold, minLineLength=, maxLineGap=).
+ * out receives up to `capacity` rows of (x1, y1, x2, y2) in OpenCV's detection
+ * order; *n is the number found (LC_ECAP if it exceeds capacity).
+ * Replaces: Simple Lane Detection with OpenCV_2(images).py:84-92,
+ *           Simple Lane Detection with OpenCV_5(mp4).py:76-84. */
+int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride,
+                     double rho, double theta, int threshold,
+                     double min_line_length, double max_line_gap,
+                     int32_t *out, int capacity, int *n);
+
+/* ---- batched pipeline (device-resident, asynchronous) -------------------- */
+
+typedef struct lc_pipe_params {
+    int width, height;        /* frame size */
+    int max_batch;            /* frames per submit, upper bound */
+    int nslots;               /* independent in-flight batches (each with its own HIP stream) */
+    int color_code;           /* LC_COLOR_BGR2GRAY or LC_COLOR_RGB2GRAY */
+    int blur;                 /* 1: GaussianBlur 5x5 between gray and Canny (F1 recipe) */
+    double canny_lo, canny_hi;
+    const uint8_t *roi_mask;  /* host, w*h, result of the script's fillPoly; NULL = no ROI */
+    const uint8_t *car_mask;  /* host, w*h, applied as bitwise_and(e, e, mask=); NULL = none */
+    double rho, theta;
+    int threshold;
+    double min_line_length, max_line_gap;
+    int seg_capacity;         /* segments kept per frame */
+    int want_accumulator;     /* compute the full-vote accumulator */
+    int want_segments;        /* run HoughLinesP */
+    int keep_intermediates;   /* also materialise gray, blurred and pre-ROI edge images */
+} lc_pipe_params;
+
+/* What lc_pipe_read copies out of a finished slot. */
+#define LC_BUF_GRAY     1     /* uint8  [n][h][w]   (keep_intermediates) */
+#define LC_BUF_BLUR     2     /* uint8  [n][h][w]   (keep_intermediates, blur) */
+#define LC_BUF_EDGES    3     /* uint8  [n][h][w]   Canny output before the masks (keep_intermediates) */
+#define LC_BUF_MASKED   4     /* uint8  [n][h][w]   edge map after car mask and ROI */
+#define LC_BUF_ACC      5     /* int32  [n][numangle][numrho] (want_accumulator) */
+#define LC_BUF_NPOINTS  6     /* int32  [n]         non-zero pixels of the masked edge map */
+
+/* Stages timed with HIP events on the slot's stream (lc_pipe_stage_ms). */
+#define LC_STAGE_UPLOAD 0
+#define LC_STAGE_EDGE   1     /* gray (+blur) + Sobel + NMS + hysteresis + masks */
+#define LC_STAGE_POINTS 2     /* ordered compaction of the edge points */
+#define LC_STAGE_VOTE   3     /* full-vote accumulator */
+#define LC_STAGE_LINES  4     /* HoughLinesP */
+#define LC_STAGE_TOTAL  5
+#define LC_NUM_STAGES   6
+
+int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out);
+int lc_pipe_destroy(lc_pipe *pipe);
+
+/* Copies nframes BGR frames from host memory (pinned for true overlap) to the
+ * slot on its stream and enqueues the whole pipeline behind the copy. */
+int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes);
+/* Same, but the frames already sit in device memory (no copy is made; the
+ * buffer must stay valid until lc_pipe_wait returns). */
+int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nframes);
+/* Blocks until the slot is done, then copies the segments out:
+ * seg_xyxy [nframes][seg_capacity][4] int32, seg_count [nframes] int32 (either may be NULL).
+ * A frame with more than seg_capacity segments reports its true count. */
+int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count);
+int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes);
+int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms);
+/* Device pointer of a slot's own input buffer (for callers that fill it on the device). */
+int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANECV_H */

@@ -1,0 +1,216 @@
+"""GPU parity of the cv2-shaped per-op calls (through the C ABI) against the CPU
+oracle: bit-exact for every image, accumulator and segment list."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(960, 540), (641, 359), (64, 48), (33, 7), (5, 5), (3, 3), (1, 9), (9, 1), (1, 1), (130, 70)]
+
+
+@pytest.fixture(scope="module")
+def cv2():
+    import lanecv
+    return lanecv
+
+
+def _frames(w, h):
+    from lanecv import synth
+    fr = dict(synth.adversarial_frames(w, h))
+    fr["road"] = synth.synth_road(w, h, seed=5, t=3)
+    return fr
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_gray_blur_canny(cv2, oracle, w, h):
+    for name, f in _frames(w, h).items():
+        for code in (cv2.COLOR_BGR2GRAY, cv2.COLOR_RGB2GRAY):
+            g = cv2.cvtColor(f, code)
+            assert g.dtype == np.uint8 and g.shape == (h, w)
+            assert (g == oracle.cvt_gray(f, code)).all(), (name, code)
+        b = cv2.GaussianBlur(g, (5, 5), 0)
+        assert (b == oracle.gaussian5(g)).all(), name
+        for src in (g, b):
+            for lo, hi in ((100, 200), (50, 150), (0, 0), (20, 600), (200, 100)):
+                e = cv2.Canny(src, lo, hi)
+                assert (e == oracle.canny(src, lo, hi)).all(), (name, lo, hi)
+
+
+def test_canny_1080p_and_4k(cv2, oracle):
+    from lanecv import synth
+    for (w, h, seed) in ((1920, 1080, 3), (3840, 2160, 4)):
+        g = oracle.gaussian5(oracle.cvt_gray(synth.synth_road(w, h, seed, 0), 6))
+        assert (cv2.Canny(g, 50, 150) == oracle.canny(g, 50, 150)).all()
+        assert (cv2.Canny(g, 100, 200) == oracle.canny(g, 100, 200)).all()
+
+
+def test_canny_long_weak_chains(cv2, oracle):
+    # a serpentine weak ridge that crosses many 64-pixel tiles with one strong seed at its end:
+    # hysteresis must carry the seed through every tile border it crosses
+    h, w = 300, 700
+    im = np.zeros((h, w), np.float32)
+    for k, y in enumerate(range(20, 280, 24)):
+        im[y:y + 12, 10:w - 10] = 30
+        x = w - 22 if k % 2 == 0 else 10
+        im[y + 12:y + 24, x:x + 12] = 30
+    im[20:32, 10:40] = 255
+    img = im.astype(np.uint8)
+    for lo, hi in ((20, 600), (50, 500), (100, 200)):
+        assert (cv2.Canny(img, lo, hi) == oracle.canny(img, lo, hi)).all()
+    rng = np.random.default_rng(1)
+    noise = rng.integers(0, 256, (500, 900), dtype=np.uint8)
+    sm = oracle.gaussian5(oracle.gaussian5(noise))
+    for lo, hi in ((5, 60), (10, 40), (30, 90)):
+        assert (cv2.Canny(sm, lo, hi) == oracle.canny(sm, lo, hi)).all()
+
+
+def test_strided_and_dst(cv2, oracle):
+    from lanecv import synth
+    f = synth.synth_road(200, 100, 1, 0)
+    big = np.zeros((100, 300, 3), np.uint8)
+    big[:, :200] = f
+    view = big[:, :200]                      # rows strided, pixels dense
+    assert (cv2.cvtColor(view, cv2.COLOR_BGR2GRAY) == oracle.cvt_gray(f, 6)).all()
+    g = oracle.cvt_gray(f, 6)
+    assert (cv2.Canny(g[:, ::2], 100, 200) == oracle.canny(np.ascontiguousarray(g[:, ::2]), 100, 200)).all()
+    dst = np.empty((100, 200), np.uint8)
+    out = cv2.GaussianBlur(g, (5, 5), 0, dst)
+    assert out is dst and (dst == oracle.gaussian5(g)).all()
+
+
+POLYS = [
+    [(0, 540), (480, 270), (960, 540)],
+    [(96, 540), (480, 270), (864, 540)],
+    [(0, 540), (960, 540), (960, 216), (0, 216)],
+    [(115, 540), (115, 216), (307, 216), (336, 270), (336, 259), (624, 259),
+     (624, 270), (652, 216), (844, 216), (844, 540)],
+    [(-50, 100), (300, -40), (1200, 300), (500, 700)],
+    [(10, 10), (200, 300), (10, 300), (200, 10)],
+    [(5, 5)], [(5, 5), (100, 50)],
+]
+
+
+@pytest.mark.parametrize("poly", POLYS)
+def test_fill_poly(cv2, oracle, poly):
+    a = np.zeros((540, 960), np.uint8)
+    b = np.zeros((540, 960), np.uint8)
+    r = cv2.fillPoly(a, np.array([poly], np.int32), 255)
+    assert r is a
+    oracle.fill_poly(b, [np.array(poly)], 255)
+    assert (a == b).all()
+    # int64 vertices (numpy default on Linux) are accepted
+    c = np.zeros((540, 960), np.uint8)
+    cv2.fillPoly(c, np.array([poly]), 255)
+    assert (c == b).all()
+
+
+def test_fill_poly_random(cv2, oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        w, h = int(rng.integers(20, 200)), int(rng.integers(20, 150))
+        n = int(rng.integers(3, 8))
+        pts = np.stack([rng.integers(-30, w + 30, n), rng.integers(-30, h + 30, n)], 1).astype(np.int32)
+        a = np.zeros((h, w), np.uint8)
+        b = np.zeros((h, w), np.uint8)
+        cv2.fillPoly(a, [pts], 200)
+        oracle.fill_poly(b, [pts], 200)
+        assert (a == b).all(), pts.tolist()
+
+
+def test_f1_masks(cv2, oracle):
+    from lanecv.pipeline import f1_car_mask
+    w, h = 640, 360
+    m = f1_car_mask(w, h)
+    ref = np.full((h, w), 255, np.uint8)
+    pts = np.array([[int(w * 0.12), h], [int(w * 0.12), int(h * 0.40)], [int(w * 0.32), int(h * 0.40)],
+                    [int(w * 0.35), int(h * 0.50)], [int(w * 0.35), int(h * 0.48)], [int(w * 0.65), int(h * 0.48)],
+                    [int(w * 0.65), int(h * 0.50)], [int(w * 0.68), int(h * 0.40)], [int(w * 0.88), int(h * 0.40)],
+                    [int(w * 0.88), h]], np.int32)
+    oracle.fill_poly(ref, [pts], 0)
+    ui_h = int(h * 0.35)
+    oracle.rectangle_filled(ref, (0, h - ui_h), (int(w * 0.12), h), 0)
+    oracle.rectangle_filled(ref, (int(w * 0.88), h - ui_h), (w, h), 0)
+    assert (m == ref).all()
+
+
+def test_bitwise_and(cv2, oracle):
+    rng = np.random.default_rng(0)
+    for (w, h) in ((960, 540), (37, 11), (1, 1)):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        b = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        m = (rng.random((h, w)) < 0.5).astype(np.uint8) * rng.integers(1, 256, (h, w), dtype=np.uint8)
+        assert (cv2.bitwise_and(a, b) == (a & b)).all()
+        assert (cv2.bitwise_and(a, a, mask=m) == oracle.bitwise_and(a, a, m)).all()
+        assert (cv2.bitwise_and(a, b, mask=m) == np.where(m != 0, a & b, 0)).all()
+
+
+def _masked(oracle, w, h, seed, t=0, code=7, blur=False, lo=100, hi=200):
+    from lanecv import synth
+    f = synth.synth_road(w, h, seed, t)
+    g = oracle.cvt_gray(f, code)
+    if blur:
+        g = oracle.gaussian5(g)
+    e = oracle.canny(g, lo, hi)
+    roi = np.zeros((h, w), np.uint8)
+    oracle.fill_poly(roi, [np.array([(0, h), (w // 2, h // 2), (w, h)])], 255)
+    return oracle.bitwise_and(e, roi)
+
+
+@pytest.mark.parametrize("w,h", [(960, 540), (1280, 720), (1920, 1080), (641, 359)])
+def test_hough_accumulator(cv2, oracle, w, h):
+    m = _masked(oracle, w, h, 2)
+    acc = cv2.hough_accumulator(m, 6, np.pi / 60)
+    ref = oracle.hough_accum(m, 6, np.pi / 60)
+    assert acc.shape == ref.shape and (acc == ref).all()
+    assert (acc.sum(axis=1) == np.count_nonzero(m)).all()
+    e = (np.random.default_rng(0).random((90, 120)) < 0.2).astype(np.uint8) * 255
+    for rho, theta in ((1, np.pi / 180), (2.5, 0.1)):
+        assert (cv2.hough_accumulator(e, rho, theta) == oracle.hough_accum(e, rho, theta)).all()
+
+
+@pytest.mark.parametrize("w,h,thr,gap", [(960, 540, 160, 25), (1280, 720, 130, 150), (1920, 1080, 160, 25),
+                                         (641, 359, 60, 25), (320, 180, 30, 5)])
+def test_hough_lines_p(cv2, oracle, w, h, thr, gap):
+    for seed in (1, 2):
+        m = _masked(oracle, w, h, seed)
+        got = cv2.HoughLinesP(m, 6, np.pi / 60, thr, lines=np.array([]), minLineLength=40, maxLineGap=gap)
+        ref = oracle.hough_lines_p(m, 6, np.pi / 60, thr, 40, gap)
+        assert (got is None) == (ref is None)
+        if ref is not None:
+            assert got.shape == ref.shape and got.dtype == np.int32 and (got == ref).all()
+
+
+def test_hough_lines_p_dense_and_empty(cv2, oracle):
+    assert cv2.HoughLinesP(np.zeros((50, 60), np.uint8), 6, np.pi / 60, 10, minLineLength=5, maxLineGap=5) is None
+    rng = np.random.default_rng(4)
+    for k in range(3):
+        e = (rng.random((60, 80)) < 0.08).astype(np.uint8) * 255
+        e[10 + k, 5:70] = 255
+        e[5:55, 20 + 3 * k] = 255
+        got = cv2.HoughLinesP(e, 1, np.pi / 180, 25, minLineLength=15, maxLineGap=2)
+        ref = oracle.hough_lines_p(e, 1, np.pi / 180, 25, 15, 2)
+        assert (got == ref).all()
+    full = np.full((40, 50), 255, np.uint8)
+    got = cv2.HoughLinesP(full, 1, np.pi / 180, 20, minLineLength=10, maxLineGap=1)
+    ref = oracle.hough_lines_p(full, 1, np.pi / 180, 20, 10, 1)
+    assert got.shape == ref.shape and (got == ref).all()
+
+
+def test_errors(cv2):
+    g = np.zeros((10, 10), np.uint8)
+    with pytest.raises(Exception):
+        cv2.cvtColor(g, cv2.COLOR_BGR2GRAY)                 # not 3-channel
+    with pytest.raises(cv2.error):
+        cv2.cvtColor(np.zeros((4, 4, 3), np.uint8), 40)     # unsupported code
+    with pytest.raises(cv2.error):
+        cv2.GaussianBlur(g, (3, 3), 0)
+    with pytest.raises(cv2.error):
+        cv2.Canny(g, 1, 2, apertureSize=5)
+    with pytest.raises(cv2.error):
+        cv2.Canny(g.astype(np.float32), 1, 2)
+    with pytest.raises(cv2.error):
+        cv2.fillPoly(g, [np.array([[0.5, 1.0], [2.0, 3.0], [3.0, 1.0]])], 255)
+    with pytest.raises(cv2.error):
+        cv2.HoughLinesP(g, 0, np.pi / 60, 10)
+    with pytest.raises(cv2.error):
+        cv2.bitwise_and(g, np.zeros((5, 5), np.uint8))

@@ -1,0 +1,136 @@
+"""GPU parity of the batched pipeline (C ABI lc_pipe_*) against the CPU oracle,
+recipe by recipe: gray, blurred, edge, masked images, the full-vote accumulator
+and the HoughLinesP segments are all compared bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_frame(oracle, f, rec, roi, car=None):
+    return oracle.lane_frame(f, rec.color_code, rec.blur, rec.canny[0], rec.canny[1], roi, rec.rho, rec.theta,
+                             rec.threshold, rec.min_line_length, rec.max_line_gap, car_mask=car,
+                             want_acc=True, want_segments=True)
+
+
+def _check_batch(oracle, pipe, frames, rec, slot=0, check_inter=True):
+    from lanecv import _abi
+    pipe.submit(slot, frames)
+    segs = pipe.collect(slot) if rec.segments else (pipe.wait(slot), None)[1]
+    masked = pipe.read(slot, _abi.BUF_MASKED)
+    inter = {}
+    if check_inter:
+        inter["gray"] = pipe.read(slot, _abi.BUF_GRAY)
+        inter["edges"] = pipe.read(slot, _abi.BUF_EDGES)
+        if rec.blur:
+            inter["blur"] = pipe.read(slot, _abi.BUF_BLUR)
+    acc = pipe.read(slot, _abi.BUF_ACC) if rec.accumulator else None
+    npts = pipe.read(slot, _abi.BUF_NPOINTS) if (rec.accumulator or rec.segments) else None
+    for i, f in enumerate(frames):
+        r = _oracle_frame(oracle, f, rec, pipe.roi, rec.car_mask)
+        for k, v in inter.items():
+            assert (v[i] == r[k]).all(), (i, k)
+        assert (masked[i] == r["masked"]).all(), i
+        if acc is not None:
+            assert (acc[i] == r["acc"]).all(), i
+        if npts is not None:
+            assert npts[i] == np.count_nonzero(r["masked"])
+        if rec.segments:
+            want = r["segments"]
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == want.shape and (got == want).all(), i
+
+
+@pytest.mark.parametrize("w,h,name", [(960, 540, "simple"), (1280, 720, "curve"), (1920, 1080, "north_star"),
+                                      (640, 360, "f1"), (641, 359, "north_star"), (130, 70, "simple")])
+def test_recipe_parity(oracle, w, h, name):
+    from lanecv import synth
+    from lanecv.pipeline import LanePipeline, Recipe
+    rec = getattr(Recipe, name)(w, h)
+    if name != "f1":
+        rec.accumulator = True
+    if w < 200:
+        rec.threshold, rec.min_line_length = 20, 10
+    pipe = LanePipeline(w, h, rec, max_batch=4, nslots=2, seg_capacity=2048, keep_intermediates=True)
+    frames = np.stack([synth.synth_road(w, h, seed=9, t=t) for t in range(3)])
+    _check_batch(oracle, pipe, frames, rec, slot=0)
+    adv = synth.adversarial_frames(w, h)
+    frames = np.stack([adv["ramps"], adv["border_impulses"], adv["black"], adv["checker3"]])
+    _check_batch(oracle, pipe, frames, rec, slot=1)
+    pipe.close()
+
+
+def test_roi_matches_fillpoly_of_the_scripts(oracle):
+    from lanecv.pipeline import LanePipeline, Recipe
+    for (w, h) in ((960, 540), (1920, 1080), (641, 359)):
+        pipe = LanePipeline(w, h, Recipe.simple(w, h), max_batch=1, nslots=1)
+        roi = np.zeros((h, w), np.uint8)
+        oracle.fill_poly(roi, [np.array([(0, h), (w / 2, h / 2), (w, h)]).astype(np.int32)], 255)
+        assert (pipe.roi == roi).all()
+        pipe.close()
+
+
+def test_slots_overlap_and_reuse(oracle):
+    """Three slots in flight at once, each reused: results must not depend on the slot or the order."""
+    from lanecv import synth
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h = 960, 540
+    rec = Recipe.north_star(w, h)
+    pipe = LanePipeline(w, h, rec, max_batch=8, nslots=3)
+    pinned = [pipe.pinned_frames(8) for _ in range(3)]
+    batches = []
+    for b in range(6):
+        fr = np.stack([synth.synth_road(w, h, seed=20 + b, t=t) for t in range(8 if b != 4 else 3)])
+        batches.append(fr)
+    results = {}
+    inflight = []
+    for b, fr in enumerate(batches):
+        slot = b % 3
+        if len(inflight) == 3:
+            ob, oslot = inflight.pop(0)
+            results[ob] = pipe.collect(oslot)
+        pinned[slot][:len(fr)] = fr
+        pipe.submit(slot, pinned[slot][:len(fr)])
+        inflight.append((b, slot))
+    for ob, oslot in inflight:
+        results[ob] = pipe.collect(oslot)
+    for b, fr in enumerate(batches):
+        assert len(results[b]) == len(fr)
+        for i, f in enumerate(fr):
+            want = _oracle_frame(oracle, f, rec, pipe.roi)["segments"]
+            got = np.zeros((0, 4), np.int32) if results[b][i] is None else results[b][i].reshape(-1, 4)
+            assert got.shape == want.shape and (got == want).all(), (b, i)
+    assert pipe.stage_ms(0, 1) > 0
+    pipe.close()
+
+
+def test_full_size_properties():
+    """BASELINE sizes beyond what the oracle checks in seconds: size-independent properties.
+    1080p batch of 32 and 4K batch of 4: accumulator rows each sum to the number of edge points;
+    every segment ends on edge pixels inside the ROI and obeys the length rule; identical frames
+    give identical results; masked edges are 0/255 and vanish outside the ROI."""
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    for (w, h, n) in ((1920, 1080, 32), (3840, 2160, 4)):
+        rec = Recipe.north_star(w, h)
+        pipe = LanePipeline(w, h, rec, max_batch=n, nslots=1)
+        base = [synth.synth_road(w, h, seed=3, t=t) for t in range(4)]
+        frames = np.stack([base[i % 4] for i in range(n)])
+        pipe.submit(0, frames)
+        segs = pipe.collect(0)
+        masked = pipe.read(0, _abi.BUF_MASKED)
+        acc = pipe.read(0, _abi.BUF_ACC)
+        npts = pipe.read(0, _abi.BUF_NPOINTS)
+        assert set(np.unique(masked)) <= {0, 255}
+        assert not masked[:, pipe.roi == 0].any()
+        for i in range(n):
+            assert npts[i] == np.count_nonzero(masked[i]) and npts[i] > 0
+            assert (acc[i].sum(axis=1) == npts[i]).all()
+            assert segs[i] is not None
+            for x1, y1, x2, y2 in segs[i].reshape(-1, 4):
+                assert masked[i, y1, x1] and masked[i, y2, x2]
+                assert max(abs(x2 - x1), abs(y2 - y1)) >= 40
+            j = i % 4
+            assert (masked[i] == masked[j]).all() and (acc[i] == acc[j]).all()
+            assert (segs[i] == segs[j]).all()
+        pipe.close()
