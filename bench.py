@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Lane-pipeline benchmark (BASELINE.json metric: 1080p lane-pipeline frames/sec + achieved HBM GB/s).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the hot path (BGR2GRAY -> 5x5 blur -> Canny -> triangle ROI -> full-vote
+accumulator -> HoughLinesP) over one batch of 256 synthetic 1080p road frames that already sit in HBM
+when the timed region starts.  Each rank owns one GPU and its own clip (seeds 100 + rank); there is no
+data-path collective, only a final gather of the per-frame segment lists to rank 0 (weak scaling).
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "image-processing_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+W, H, BATCH, NSLOTS, SEG_CAP = 1920, 1080, 256, 3, 128
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak
+
+
+def _gen(args):
+    from lanecv import synth
+    seed, t = args
+    return synth.synth_road(W, H, seed, t)
+
+
+def make_frames(seed, n, workers):
+    """n distinct frames of one clip, generated before anything touches the GPU."""
+    import numpy as np
+    import multiprocessing as mp
+    jobs = [(seed, t) for t in range(n)]
+    if workers > 1:
+        with mp.get_context("fork").Pool(workers) as pool:
+            frames = pool.map(_gen, jobs, chunksize=4)
+    else:
+        frames = [_gen(j) for j in jobs]
+    return np.stack(frames)
+
+
+def cpu_baseline(frames, rec, roi, threads):
+    """The CPU oracle (a scalar C port of the OpenCV arithmetic), frame-parallel over `threads` host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import lane_oracle as lo
+    lo.lib()
+
+    def one(f):
+        lo.lane_frame(f, rec.color_code, rec.blur, rec.canny[0], rec.canny[1], roi, rec.rho, rec.theta,
+                      rec.threshold, rec.min_line_length, rec.max_line_gap, want_acc=True, want_segments=True)
+
+    one(frames[0])
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(one, frames))
+    dt = time.perf_counter() - t0
+    return len(frames) / dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--slots", type=int, default=NSLOTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    batch = args.batch
+
+    import numpy as np
+    host_threads = min(16, os.cpu_count() or 1)
+    frames = make_frames(100 + rank, batch, host_threads)        # clip `100 + rank`, frames t = 0..batch-1
+
+    import torch                       # first: liblanecv.so then binds to the HIP runtime torch loaded
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from lanecv import _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    rec = Recipe.north_star(W, H)
+    pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=args.slots, seg_capacity=SEG_CAP, device=local_rank)
+
+    dev_frames = torch.from_numpy(frames).cuda()                 # inputs resident in HBM
+    torch.cuda.synchronize()
+    ptr = dev_frames.data_ptr()
+
+    results = {}
+    stage_names = {"front": _abi.STAGE_FRONT, "hyst": _abi.STAGE_HYST, "final": _abi.STAGE_FINAL,
+                   "edge": _abi.STAGE_EDGE, "points": _abi.STAGE_POINTS, "vote": _abi.STAGE_VOTE,
+                   "lines": _abi.STAGE_LINES, "total": _abi.STAGE_TOTAL}
+
+    def run(steps, collect_stages=None):
+        inflight = []
+        for k in range(steps):
+            slot = k % args.slots
+            if len(inflight) == args.slots:
+                s = inflight.pop(0)
+                results[s] = pipe.wait(s)
+                if collect_stages is not None:
+                    collect_stages.append({n: pipe.stage_ms(s, i) for n, i in stage_names.items()})
+            pipe.submit_device(slot, ptr, batch)
+            inflight.append(slot)
+        for s in inflight:
+            results[s] = pipe.wait(s)
+            if collect_stages is not None:
+                collect_stages.append({n: pipe.stage_ms(s, i) for n, i in stage_names.items()})
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    run(args.warmup)
+    stages = []
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, stages)
+    # final result gather: per-frame segment counts and padded segment lists of the last batch to rank 0
+    seg, cnt = results[(args.steps - 1) % args.slots]
+    if world > 1:
+        seg_t = torch.from_numpy(seg).cuda()
+        cnt_t = torch.from_numpy(cnt).cuda()
+        seg_all = [torch.empty_like(seg_t) for _ in range(world)] if rank == 0 else None
+        cnt_all = [torch.empty_like(cnt_t) for _ in range(world)] if rank == 0 else None
+        dist.gather(seg_t, seg_all, dst=0)
+        dist.gather(cnt_t, cnt_all, dst=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    fps = world * args.steps * batch / dt
+
+    out = None
+    if rank == 0:
+        mean = {n: float(np.mean([s[n] for s in stages])) for n in stage_names}
+        edge_ms = mean["front"] + mean["hyst"] + mean["final"]
+        alg_bytes = 4.0 * W * H * batch            # 3 B/px BGR in + 1 B/px masked edge map out, per launch of the stage
+        achieved = alg_bytes / (edge_ms * 1e-3) / 1e9
+        out = {
+            "metric": "1080p lane-pipeline frames/sec", "value": round(fps, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "synthetic 1080p road frames (BASELINE configs[2]), batch=%d per step, recipe north_star: "
+                                   "BGR2GRAY -> GaussianBlur 5x5 -> Canny(100,200) -> triangle ROI -> full-vote accumulator "
+                                   "-> HoughLinesP(6, pi/60, 160, 40, 25); inputs resident in HBM" % batch,
+                       "width": W, "height": H, "batch": batch, "slots_in_flight": args.slots,
+                       "sharding": "one clip per GPU, no data-path collective, final segment gather"},
+            "roofline": {"bound": "hbm", "kernel": "edge stage = k_front + k_hyst_first + k_hyst_close + k_finalize",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(edge_ms, 4),
+                         "note": "durations are HIP-event times on the slot's stream inside the timed region, "
+                                 "with %d batches in flight on separate streams" % args.slots},
+            "stage_ms": {k: round(v, 4) for k, v in mean.items()},
+            "segments_frame0": int(cnt[0]), "hyst_closure_rounds_max_total": list(pipe.hyst_rounds(0)),
+        }
+
+        # exclusive timings: one batch in flight, nothing else on the GPU
+        excl = []
+        for _ in range(5):
+            pipe.submit_device(0, ptr, batch)
+            pipe.wait(0)
+            excl.append({n: pipe.stage_ms(0, i) for n, i in stage_names.items()})
+        em = {n: float(np.median([s[n] for s in excl])) for n in stage_names}
+        e_ms = em["front"] + em["hyst"] + em["final"]
+        out["roofline_exclusive"] = {"launch_ms": round(e_ms, 4), "achieved": round(alg_bytes / (e_ms * 1e-3) / 1e9, 1),
+                                     "frac": round(alg_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "stage_ms": {k: round(v, 4) for k, v in em.items()}}
+
+        if not args.no_streaming:
+            # PCIe-inclusive rate: pinned host ring -> hipMemcpyAsync -> pipeline, slots overlapped (never `value`)
+            pinned = [pipe.pinned_frames(batch) for _ in range(args.slots)]
+            for p in pinned:
+                p[:] = frames
+            ssteps = max(args.slots * 2, 6)
+            t1 = time.perf_counter()
+            inflight = []
+            for k in range(ssteps):
+                slot = k % args.slots
+                if len(inflight) == args.slots:
+                    pipe.wait(inflight.pop(0))
+                pipe.submit(slot, pinned[slot])
+                inflight.append(slot)
+            for s in inflight:
+                pipe.wait(s)
+            out["streaming_fps_pcie_inclusive"] = round(ssteps * batch / (time.perf_counter() - t1), 1)
+
+        if world == 1 and not args.no_cpu_baseline:
+            sample = frames[:min(batch, 128)]
+            v = cpu_baseline(sample, rec, pipe.roi, host_threads)
+            out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": host_threads, "kind": "port",
+                                   "sample": "%d of the same 1080p frames through the same recipe with the scalar C oracle "
+                                             "(cv2 is not installed on this image), frame-parallel over %d threads"
+                                             % (len(sample), host_threads)}
+        print(json.dumps(out), flush=True)
+
+    pipe.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

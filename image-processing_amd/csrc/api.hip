@@ -36,7 +36,6 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr int MAX_DIM = 8192;       // 16.16 walk arithmetic and the packed (x | y << 16) points need this bound
-constexpr int HYST_CHUNK = 4;       // hysteresis rounds enqueued between two convergence checks
 
 template <typename T>
 struct DevBuf {
@@ -100,7 +99,8 @@ struct Work {
     bool inter = false;
     DevBuf<uint8_t> bgr, gray, blur, edges, masked;
     DevBuf<uint64_t> planeS, planeW, rowplane;
-    DevBuf<int> act, nact, rowcount, rowoff, npoints, segcount, status;
+    DevBuf<uint8_t> wake;
+    DevBuf<int> rounds, rowcount, rowoff, npoints, segcount, status;
     DevBuf<uint32_t> nz;
     int nz_cap = 0;
     DevBuf<int32_t> acc_full, acc_ppht, seg;
@@ -125,8 +125,8 @@ struct Work {
         if ((rc = planeS.alloc((size_t)B * g.plane_words()))) return rc;
         if ((rc = planeW.alloc((size_t)B * g.plane_words()))) return rc;
         if ((rc = rowplane.alloc((size_t)B * g.rowplane_words()))) return rc;
-        if ((rc = act.alloc((size_t)B * g.TX * g.TY))) return rc;
-        if ((rc = nact.alloc(HYST_CHUNK + 2))) return rc;
+        if ((rc = wake.alloc((size_t)B * g.TX * g.TY))) return rc;
+        if ((rc = rounds.alloc(B))) return rc;
         if ((rc = rowcount.alloc((size_t)B * H))) return rc;
         if ((rc = rowoff.alloc((size_t)B * H))) return rc;
         if ((rc = npoints.alloc(B))) return rc;
@@ -159,32 +159,6 @@ struct Work {
         return LC_OK;
     }
 };
-
-// Runs hysteresis rounds [r0, r0 + n) on the stream; nact_dev[k] (k = 1..n) receives
-// the number of wake-ups made by round r0 + k - 1.
-void enqueue_hyst(Work &w, int nframes, int r0, int n, hipStream_t st) {
-    (void)hipMemsetAsync(w.nact.p, 0, sizeof(int) * (HYST_CHUNK + 2), st);
-    for (int r = r0; r < r0 + n; r++)
-        launch_hyst_round(w.g, nframes, r, w.planeS.p, w.planeW.p, w.act.p, w.nact.p - r0, st);
-}
-
-bool chunk_converged(const int *nact_host, int n) {
-    for (int k = 1; k <= n; k++)
-        if (nact_host[k] == 0) return true;
-    return false;
-}
-
-// Synchronous hysteresis to the fixed point (used by the per-op calls).
-int hysteresis_sync(Work &w, int nframes, hipStream_t st) {
-    HIP_TRY(hipMemsetAsync(w.act.p, 0, sizeof(int) * (size_t)w.B * w.g.TX * w.g.TY, st));
-    int host[HYST_CHUNK + 2];
-    for (int r0 = 0;; r0 += HYST_CHUNK) {
-        enqueue_hyst(w, nframes, r0, HYST_CHUNK, st);
-        HIP_TRY(hipMemcpyAsync(host, w.nact.p, sizeof host, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (chunk_converged(host, HYST_CHUNK)) return LC_OK;
-    }
-}
 
 }  // namespace
 
@@ -400,7 +374,7 @@ int lc_canny(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, d
     if ((rc = up2d(ctx->tmpA.p, src, w, h, src_stride, ctx->stream))) return rc;
     launch_front(ctx->tmpA.p, (size_t)w * h, 0, LC_COLOR_BGR2GRAY, false, wk.g, 1, low, high, wk.planeS.p, wk.planeW.p,
                  nullptr, nullptr, ctx->stream);
-    if ((rc = hysteresis_sync(wk, 1, ctx->stream))) return rc;
+    launch_hysteresis(wk.g, 1, wk.planeS.p, wk.planeW.p, wk.wake.p, wk.rounds.p, ctx->stream);
     launch_finalize(wk.g, 1, wk.planeS.p, nullptr, ctx->tmpB.p, nullptr, nullptr, nullptr, ctx->stream);
     return down2d(dst, dst_stride, ctx->tmpB.p, w, h, ctx->stream);
 }
@@ -582,15 +556,14 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
 struct Slot {
     Work w;
     hipStream_t st = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     int nframes = 0;
     const uint8_t *input = nullptr;   // device pointer of the frames of the batch in flight
     size_t input_bytes = 0;
     bool busy = false, timed = false;
     // pinned host staging
-    int *h_nact = nullptr, *h_status = nullptr, *h_segcount = nullptr;
+    int *h_rounds = nullptr, *h_status = nullptr, *h_segcount = nullptr;
     int32_t *h_seg = nullptr;
-    int rounds_done = 0;
 };
 
 struct lc_pipe {
@@ -605,7 +578,7 @@ struct lc_pipe {
 
 namespace {
 
-enum { EV_START = 0, EV_UPLOADED, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END };
+enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END };
 
 void enqueue_back(lc_pipe *pp, Slot &s) {
     Work &w = s.w;
@@ -636,6 +609,7 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
         (void)hipMemcpyAsync(s.h_seg, w.seg.p, sizeof(int32_t) * 4 * (size_t)n * w.seg_cap, hipMemcpyDeviceToHost, s.st);
         (void)hipMemcpyAsync(s.h_status, w.status.p, sizeof(int), hipMemcpyDeviceToHost, s.st);
     }
+    (void)hipMemcpyAsync(s.h_rounds, w.rounds.p, sizeof(int) * n, hipMemcpyDeviceToHost, s.st);
     (void)hipEventRecord(s.ev[EV_END], s.st);
 }
 
@@ -643,13 +617,12 @@ int enqueue_all(lc_pipe *pp, Slot &s) {
     Work &w = s.w;
     const lc_pipe_params &p = pp->p;
     const int n = s.nframes;
-    HIP_TRY(hipMemsetAsync(w.act.p, 0, sizeof(int) * (size_t)n * w.g.TX * w.g.TY, s.st));
     HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], s.st));
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, s.st);
-    enqueue_hyst(w, n, 0, HYST_CHUNK, s.st);
-    s.rounds_done = HYST_CHUNK;
-    HIP_TRY(hipMemcpyAsync(s.h_nact, w.nact.p, sizeof(int) * (HYST_CHUNK + 2), hipMemcpyDeviceToHost, s.st));
+    HIP_TRY(hipEventRecord(s.ev[EV_FRONT], s.st));
+    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.rounds.p, s.st);
+    HIP_TRY(hipEventRecord(s.ev[EV_HYST], s.st));
     enqueue_back(pp, s);
     HIP_TRY(hipGetLastError());
     s.busy = true;
@@ -740,8 +713,8 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             }
         }
         void *hp = nullptr;
-        if ((rc = lc_host_alloc_pinned(sizeof(int) * (HYST_CHUNK + 2), &hp))) { lc_pipe_destroy(pp); return rc; }
-        s.h_nact = (int *)hp;
+        if ((rc = lc_host_alloc_pinned(sizeof(int) * p.max_batch, &hp))) { lc_pipe_destroy(pp); return rc; }
+        s.h_rounds = (int *)hp;
         if ((rc = lc_host_alloc_pinned(sizeof(int), &hp))) { lc_pipe_destroy(pp); return rc; }
         s.h_status = (int *)hp;
         *s.h_status = 0;
@@ -761,7 +734,7 @@ int lc_pipe_destroy(lc_pipe *pipe) {
         if (s.st) { (void)hipStreamSynchronize(s.st); }
         for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
         if (s.st) (void)hipStreamDestroy(s.st);
-        if (s.h_nact) (void)hipHostFree(s.h_nact);
+        if (s.h_rounds) (void)hipHostFree(s.h_rounds);
         if (s.h_status) (void)hipHostFree(s.h_status);
         if (s.h_segcount) (void)hipHostFree(s.h_segcount);
         if (s.h_seg) (void)hipHostFree(s.h_seg);
@@ -804,19 +777,6 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
     HIP_TRY(hipStreamSynchronize(s->st));
-    if (!chunk_converged(s->h_nact, HYST_CHUNK)) {
-        // rare: a weak chain crosses more tile borders than the rounds enqueued up front
-        for (;;) {
-            enqueue_hyst(s->w, s->nframes, s->rounds_done, HYST_CHUNK, s->st);
-            s->rounds_done += HYST_CHUNK;
-            HIP_TRY(hipMemcpyAsync(s->h_nact, s->w.nact.p, sizeof(int) * (HYST_CHUNK + 2), hipMemcpyDeviceToHost, s->st));
-            HIP_TRY(hipStreamSynchronize(s->st));
-            if (chunk_converged(s->h_nact, HYST_CHUNK)) break;
-        }
-        enqueue_back(pipe, *s);
-        HIP_TRY(hipStreamSynchronize(s->st));
-        s->timed = false;   // stage events no longer bracket the whole batch
-    }
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
     if (p.want_segments) {
@@ -868,9 +828,35 @@ int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms) {
         case LC_STAGE_VOTE: a = EV_POINTS; b = EV_VOTE; break;
         case LC_STAGE_LINES: a = EV_VOTE; b = EV_LINES; break;
         case LC_STAGE_TOTAL: a = EV_START; b = EV_END; break;
+        case LC_STAGE_FRONT: a = EV_UPLOADED; b = EV_FRONT; break;
+        case LC_STAGE_HYST: a = EV_FRONT; b = EV_HYST; break;
+        case LC_STAGE_FINAL: a = EV_HYST; b = EV_EDGE; break;
         default: return fail(LC_EINVAL, "unknown stage %d", stage);
     }
     HIP_TRY(hipEventElapsedTime(ms, s->ev[a], s->ev[b]));
+    return LC_OK;
+}
+
+int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_total) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
+    int mx = 0, tot = 0;
+    for (int i = 0; i < s->nframes; i++) { mx = std::max(mx, s->h_rounds[i]); tot += s->h_rounds[i]; }
+    if (rounds_max) *rounds_max = mx;
+    if (rounds_total) *rounds_total = tot;
+    return LC_OK;
+}
+
+int lc_pipe_upload(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "upload: bad frames argument");
+    if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
+    HIP_TRY(hipMemcpyAsync(s->w.bgr.p, host_bgr, (size_t)nframes * 3 * s->w.npix, hipMemcpyHostToDevice, s->st));
+    HIP_TRY(hipStreamSynchronize(s->st));
     return LC_OK;
 }
 

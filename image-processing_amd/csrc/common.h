@@ -45,8 +45,10 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes,
                   int low, int high, uint64_t *planeS, uint64_t *planeW,
                   uint8_t *gray_out, uint8_t *blur_out, hipStream_t st);
-void launch_hyst_round(Geo g, int nframes, int round, uint64_t *planeS, const uint64_t *planeW,
-                       int *act, int *nact, hipStream_t st);
+// hysteresis to the fixed point: a chip-wide first round, then one workgroup per frame closes
+// the chains that cross tile borders; rounds[f] receives the closure rounds frame f needed
+void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint8_t *wake, int *rounds,
+                       hipStream_t st);
 // roi_bits: tile-major plane shared by all frames, or nullptr
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits,
                      uint8_t *edges_out, uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st);

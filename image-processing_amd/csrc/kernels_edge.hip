@@ -269,30 +269,35 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-constexpr int HY_WAVES = 4;
-__global__ __launch_bounds__(64 * HY_WAVES) void k_hyst(Geo g, int ntiles_total, int round, uint64_t *__restrict__ planeS,
-                                                       const uint64_t *__restrict__ planeW, int *__restrict__ act,
-                                                       int *__restrict__ nact) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * HY_WAVES + (threadIdx.x >> 6);   // global tile index over all frames
-    if (t >= ntiles_total) return;
-    if (round > 0 && act[t] != round) return;
+// L2-served accesses of the strong plane: tiles read their neighbours' words while other
+// wavefronts (possibly on other CUs) are adding bits to them.  A stale read only delays a
+// promotion to a later round, it never loses one; bits are only ever added.
+__device__ __forceinline__ uint64_t ldS(const uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stS(uint64_t *p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wavefront floods tile (ty, tx) of frame f.  Returns an 8-bit mask of the neighbours
+// (0 T, 1 B, 2 L, 3 R, 4 TL, 5 TR, 6 BL, 7 BR) that touch a pixel this call made strong.
+__device__ __forceinline__ unsigned hyst_tile(const Geo &g, int f, int ty, int tx, uint64_t *__restrict__ planeS,
+                                              const uint64_t *__restrict__ planeW, int lane) {
     const int tiles_per_frame = g.TX * g.TY;
-    const int f = t / tiles_per_frame, tt = t % tiles_per_frame;
-    const int ty = tt / g.TX, tx = tt % g.TX;
-    const size_t base = (size_t)t * TILE;
+    const size_t fb = (size_t)f * tiles_per_frame;
+    const size_t base = (fb + (size_t)ty * g.TX + tx) * TILE;
     uint64_t Wk = planeW[base + lane];
-    if (__ballot(Wk != 0) == 0) return;
-    uint64_t S = planeS[base + lane];
+    if (__ballot(Wk != 0) == 0) return 0;
+    uint64_t S = ldS(planeS + base + lane);
     Wk &= ~S;
+    if (__ballot(Wk != 0) == 0) return 0;
     const uint64_t S_in = S;
     const uint64_t cand = S | Wk;
 
-    // strong bits of the ring around the tile
-    const bool hasL = tx > 0, hasR = tx + 1 < g.TX, hasT = ty > 0, hasB = ty + 1 < g.TY;
-    const size_t fb = (size_t)f * tiles_per_frame;
-    uint64_t Lw = hasL ? planeS[(fb + (size_t)ty * g.TX + tx - 1) * TILE + lane] : 0;
-    uint64_t Rw = hasR ? planeS[(fb + (size_t)ty * g.TX + tx + 1) * TILE + lane] : 0;
+    // strong bits of the one-pixel ring around the tile
+    const bool hasL = tx > 0, hasR = tx + 1 < g.TX;
+    uint64_t Lw = hasL ? ldS(planeS + (fb + (size_t)ty * g.TX + tx - 1) * TILE + lane) : 0;
+    uint64_t Rw = hasR ? ldS(planeS + (fb + (size_t)ty * g.TX + tx + 1) * TILE + lane) : 0;
     uint64_t lcol = Lw >> 63, rcol = Rw & 1;     // (row, -1) and (row, 64)
     // lanes 0..2: row 63 of tiles (ty-1, tx-1..tx+1); lanes 3..5: row 0 of tiles (ty+1, tx-1..tx+1)
     uint64_t edge = 0;
@@ -300,9 +305,8 @@ __global__ __launch_bounds__(64 * HY_WAVES) void k_hyst(Geo g, int ntiles_total,
         int dy = lane < 3 ? -1 : 1, dx = (lane % 3) - 1;
         int yy = ty + dy, xx = tx + dx;
         if (yy >= 0 && yy < g.TY && xx >= 0 && xx < g.TX)
-            edge = planeS[(fb + (size_t)yy * g.TX + xx) * TILE + (dy < 0 ? 63 : 0)];
+            edge = ldS(planeS + (fb + (size_t)yy * g.TX + xx) * TILE + (dy < 0 ? 63 : 0));
     }
-    (void)hasT; (void)hasB;
     uint64_t tl = shfl_u64(edge, 0) >> 63, tm = shfl_u64(edge, 1), tr = shfl_u64(edge, 2) & 1;
     uint64_t bl = shfl_u64(edge, 3) >> 63, bm = shfl_u64(edge, 4), br = shfl_u64(edge, 5) & 1;
     // column neighbours of row r: rows r-1, r, r+1 of the left / right ring
@@ -329,33 +333,82 @@ __global__ __launch_bounds__(64 * HY_WAVES) void k_hyst(Geo g, int ntiles_total,
 
     const uint64_t added = S & ~S_in;
     const uint64_t any = __ballot(added != 0);
-    if (any == 0) return;
-    if (added) planeS[base + lane] = S;
-    // wake the neighbours that touch a newly strong border pixel
+    if (any == 0) return 0;
+    if (added) stS(planeS + base + lane, S);
     const bool top = (any & 1) != 0, bot = (any >> 63) != 0;
     const bool left = __ballot((added & 1) != 0) != 0, right = __ballot((added >> 63) != 0) != 0;
     const uint64_t a0 = shfl_u64(added, 0), a63 = shfl_u64(added, 63);
-    if (lane < 8) {
-        // neighbour order: 0 T, 1 B, 2 L, 3 R, 4 TL, 5 TR, 6 BL, 7 BR
-        const int dys[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
-        const int dxs[8] = {0, 0, -1, 1, -1, 1, -1, 1};
-        bool want;
-        switch (lane) {
-            case 0: want = top; break;
-            case 1: want = bot; break;
-            case 2: want = left; break;
-            case 3: want = right; break;
-            case 4: want = top && (a0 & 1); break;
-            case 5: want = top && (a0 >> 63); break;
-            case 6: want = bot && (a63 & 1); break;
-            default: want = bot && (a63 >> 63); break;
-        }
-        int yy = ty + dys[lane], xx = tx + dxs[lane];
-        if (want && yy >= 0 && yy < g.TY && xx >= 0 && xx < g.TX) {
-            act[fb + (size_t)yy * g.TX + xx] = round + 1;
-            atomicAdd(&nact[round + 1], 1);
-        }
+    unsigned m = 0;
+    if (top && ty > 0) m |= 1u;
+    if (bot && ty + 1 < g.TY) m |= 2u;
+    if (left && hasL) m |= 4u;
+    if (right && hasR) m |= 8u;
+    if (top && (a0 & 1) && ty > 0 && hasL) m |= 16u;
+    if (top && (a0 >> 63) && ty > 0 && hasR) m |= 32u;
+    if (bot && (a63 & 1) && ty + 1 < g.TY && hasL) m |= 64u;
+    if (bot && (a63 >> 63) && ty + 1 < g.TY && hasR) m |= 128u;
+    return m;
+}
+
+__device__ __forceinline__ int nb_tile(const Geo &g, int ty, int tx, int k) {
+    const int dys[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
+    const int dxs[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+    return (ty + dys[k]) * g.TX + (tx + dxs[k]);
+}
+
+// round 0: every tile of every frame, one wavefront each, the whole chip busy
+constexpr int HY_WAVES = 4;
+__global__ __launch_bounds__(64 * HY_WAVES) void k_hyst_first(Geo g, int ntiles_total, uint64_t *__restrict__ planeS,
+                                                             const uint64_t *__restrict__ planeW,
+                                                             uint8_t *__restrict__ wake) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * HY_WAVES + (threadIdx.x >> 6);   // global tile index over all frames
+    if (t >= ntiles_total) return;
+    const int tiles_per_frame = g.TX * g.TY;
+    const int f = t / tiles_per_frame, tt = t % tiles_per_frame;
+    const int ty = tt / g.TX, tx = tt % g.TX;
+    const unsigned m = hyst_tile(g, f, ty, tx, planeS, planeW, lane);
+    if (lane < 8 && ((m >> lane) & 1)) wake[(size_t)f * tiles_per_frame + nb_tile(g, ty, tx, lane)] = 1;
+}
+
+// closure: one workgroup per frame repeats rounds over the woken tiles until none is woken.
+// All cross-tile hand-offs stay inside the workgroup (barriers + L2-served plane words), so
+// the fixed point is reached on the device with no host round trip.
+constexpr int HC_THREADS = 1024;
+__global__ __launch_bounds__(HC_THREADS) void k_hyst_close(Geo g, uint64_t *__restrict__ planeS,
+                                                           const uint64_t *__restrict__ planeW,
+                                                           const uint8_t *__restrict__ wake, int *__restrict__ rounds_out) {
+    extern __shared__ uint8_t flags[];   // [2][tiles_per_frame]
+    __shared__ int any;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = g.TX * g.TY;
+    uint8_t *cur = flags, *nxt = flags + ntile;
+    int mine = 0;
+    for (int i = tid; i < ntile; i += HC_THREADS) {
+        uint8_t v = wake[(size_t)f * ntile + i];
+        cur[i] = v; nxt[i] = 0;
+        mine |= v;
     }
+    if (tid == 0) any = 0;
+    __syncthreads();
+    if (mine) any = 1;
+    __syncthreads();
+    int rounds = 0;
+    while (any) {
+        __syncthreads();
+        if (tid == 0) any = 0;
+        __syncthreads();
+        for (int t = wave; t < ntile; t += HC_THREADS / 64) {
+            if (!cur[t]) continue;
+            const int ty = t / g.TX, tx = t % g.TX;
+            const unsigned m = hyst_tile(g, f, ty, tx, planeS, planeW, lane);
+            if (lane < 8 && ((m >> lane) & 1)) { nxt[nb_tile(g, ty, tx, lane)] = 1; any = 1; }
+        }
+        __syncthreads();
+        for (int i = tid; i < ntile; i += HC_THREADS) { cur[i] = nxt[i]; nxt[i] = 0; }
+        rounds++;
+    }
+    if (tid == 0 && rounds_out) rounds_out[f] = rounds;
 }
 
 // ---------------------------------------------------------------------------
@@ -479,11 +532,12 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 #undef LC_FRONT
 }
 
-void launch_hyst_round(Geo g, int nframes, int round, uint64_t *planeS, const uint64_t *planeW, int *act, int *nact,
+void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint8_t *wake, int *rounds,
                        hipStream_t st) {
-    int nt = g.TX * g.TY * nframes;
-    hipLaunchKernelGGL(k_hyst, dim3((nt + HY_WAVES - 1) / HY_WAVES), dim3(64 * HY_WAVES), 0, st, g, nt, round, planeS, planeW,
-                       act, nact);
+    const int per = g.TX * g.TY, nt = per * nframes;
+    (void)hipMemsetAsync(wake, 0, (size_t)nt, st);
+    hipLaunchKernelGGL(k_hyst_first, dim3((nt + HY_WAVES - 1) / HY_WAVES), dim3(64 * HY_WAVES), 0, st, g, nt, planeS, planeW, wake);
+    hipLaunchKernelGGL(k_hyst_close, dim3(nframes), dim3(HC_THREADS), 2 * (size_t)per, st, g, planeS, planeW, wake, rounds);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,

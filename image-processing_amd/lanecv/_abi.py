@@ -21,7 +21,7 @@ class error(Exception):
 LC_OK, LC_EINVAL, LC_ENOMEM, LC_ECAP, LC_EHIP, LC_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 BUF_GRAY, BUF_BLUR, BUF_EDGES, BUF_MASKED, BUF_ACC, BUF_NPOINTS = 1, 2, 3, 4, 5, 6
-STAGE_UPLOAD, STAGE_EDGE, STAGE_POINTS, STAGE_VOTE, STAGE_LINES, STAGE_TOTAL = range(6)
+STAGE_UPLOAD, STAGE_EDGE, STAGE_POINTS, STAGE_VOTE, STAGE_LINES, STAGE_TOTAL, STAGE_FRONT, STAGE_HYST, STAGE_FINAL = range(9)
 
 # every symbol include/lanecv.h declares
 SYMBOLS = [
@@ -29,7 +29,7 @@ SYMBOLS = [
     "lc_cvt_gray", "lc_gaussian5", "lc_canny", "lc_fill_poly", "lc_rectangle_filled", "lc_and",
     "lc_hough_geometry", "lc_hough_accum", "lc_hough_lines_p",
     "lc_pipe_create", "lc_pipe_destroy", "lc_pipe_submit_host", "lc_pipe_submit_device", "lc_pipe_wait",
-    "lc_pipe_read", "lc_pipe_stage_ms", "lc_pipe_input_device_ptr",
+    "lc_pipe_read", "lc_pipe_stage_ms", "lc_pipe_input_device_ptr", "lc_pipe_upload", "lc_pipe_hyst_rounds",
 ]
 
 
@@ -79,6 +79,8 @@ def lib():
         L.lc_pipe_read.argtypes = [vp, i, i, vp, sz]
         L.lc_pipe_stage_ms.argtypes = [vp, i, i, C.POINTER(C.c_float)]
         L.lc_pipe_input_device_ptr.argtypes = [vp, i, C.POINTER(vp)]
+        L.lc_pipe_upload.argtypes = [vp, i, vp, i]
+        L.lc_pipe_hyst_rounds.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
         _lib = L
     return _lib
 

@@ -124,9 +124,9 @@ class LanePipeline:
         self.numangle, self.numrho = na.value, nr.value
 
     def close(self):
-        if getattr(self, "_h", None):
-            _abi.lib().lc_pipe_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _abi is not None and getattr(_abi, "_lib", None) is not None:
+            _abi._lib.lc_pipe_destroy(h)
 
     __del__ = close
 
@@ -150,6 +150,17 @@ class LanePipeline:
         _abi.check(_abi.lib().lc_pipe_submit_host(self._h, slot, _abi.ptr(frames), len(frames)))
         self._n[slot] = len(frames)
         self._keepalive = frames
+
+    def upload(self, slot, frames):
+        """Copies frames into the slot's own HBM input buffer (synchronous) and returns its device pointer;
+        `submit_device(slot, ptr, n)` then runs with the input already resident."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.shape[1:] != (self.h, self.w, 3):
+            raise error("upload: expected frames of shape (n, %d, %d, 3), got %s" % (self.h, self.w, frames.shape))
+        _abi.check(_abi.lib().lc_pipe_upload(self._h, slot, _abi.ptr(frames), len(frames)))
+        p = C.c_void_p()
+        _abi.check(_abi.lib().lc_pipe_input_device_ptr(self._h, slot, C.byref(p)))
+        return p.value
 
     def submit_device(self, slot, dev_ptr, nframes):
         """Frames already in HBM (e.g. a torch uint8 tensor's data_ptr()), [n][h][w][3] dense."""
@@ -189,6 +200,12 @@ class LanePipeline:
             out = np.empty((n, self.h, self.w), np.uint8)
         _abi.check(_abi.lib().lc_pipe_read(self._h, slot, what, _abi.ptr(out), out.nbytes))
         return out
+
+    def hyst_rounds(self, slot):
+        """(max over frames, total) cross-tile hysteresis closure rounds of the slot's last batch."""
+        a, b = C.c_int(), C.c_int()
+        _abi.check(_abi.lib().lc_pipe_hyst_rounds(self._h, slot, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def stage_ms(self, slot, stage):
         ms = C.c_float()

@@ -143,7 +143,10 @@ typedef struct lc_pipe_params {
 #define LC_STAGE_VOTE   3     /* full-vote accumulator */
 #define LC_STAGE_LINES  4     /* HoughLinesP */
 #define LC_STAGE_TOTAL  5
-#define LC_NUM_STAGES   6
+#define LC_STAGE_FRONT  6     /* part of EDGE: the fused gray/blur/Sobel/NMS kernel */
+#define LC_STAGE_HYST   7     /* part of EDGE: the hysteresis rounds */
+#define LC_STAGE_FINAL  8     /* part of EDGE: masks + 0/255 store */
+#define LC_NUM_STAGES   9
 
 int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out);
 int lc_pipe_destroy(lc_pipe *pipe);
@@ -162,6 +165,12 @@ int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes
 int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms);
 /* Device pointer of a slot's own input buffer (for callers that fill it on the device). */
 int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr);
+/* Hysteresis diagnostics of the slot's last batch: cross-tile closure rounds, maximum over the
+ * frames and total. */
+int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_total);
+/* Synchronous copy of nframes host frames into the slot's own input buffer, nothing else:
+ * a later lc_pipe_submit_device on that pointer then runs with the input resident in HBM. */
+int lc_pipe_upload(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes);
 
 #ifdef __cplusplus
 }
