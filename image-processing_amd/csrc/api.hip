@@ -35,6 +35,7 @@ int fail(int code, const char *fmt, ...) {
             return fail(LC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+constexpr int RNG_TABLE = 16384;    // covers every point count the LDS fast path of HoughLinesP accepts
 constexpr int MAX_DIM = 8192;       // 16.16 walk arithmetic and the packed (x | y << 16) points need this bound
 
 template <typename T>
@@ -100,11 +101,12 @@ struct Work {
     DevBuf<uint8_t> bgr, gray, blur, edges, masked;
     DevBuf<uint64_t> planeS, planeW, rowplane;
     DevBuf<uint8_t> wake;
-    DevBuf<int> rounds, rowcount, rowoff, npoints, segcount, status;
+    DevBuf<int> rounds, rowcount, rowoff, npoints, segcount, status, fallback;
     DevBuf<uint32_t> nz;
     int nz_cap = 0;
     DevBuf<int32_t> acc_full, acc_ppht, seg;
     DevBuf<AngleEntry> tab;
+    DevBuf<uint32_t> rng_out;     // first RNG_TABLE outputs of cv::RNG(2^64 - 1), HoughLinesP's fixed seed
     HoughGeo hg;
     double rho = 0, theta = 0;
     int seg_cap = 0;
@@ -132,6 +134,7 @@ struct Work {
         if ((rc = npoints.alloc(B))) return rc;
         if ((rc = segcount.alloc(B))) return rc;
         if ((rc = status.alloc(1))) return rc;
+        if ((rc = fallback.alloc(B))) return rc;
         return LC_OK;
     }
     int init_points(int cap) {
@@ -148,6 +151,17 @@ struct Work {
             HIP_TRY(hipStreamSynchronize(st));
             acc_full.release();
             acc_ppht.release();
+        }
+        if (ppht && !rng_out.p) {
+            std::vector<uint32_t> r(RNG_TABLE);
+            unsigned long long state = 0xFFFFFFFFFFFFFFFFull;
+            for (int k = 0; k < RNG_TABLE; k++) {
+                state = (unsigned long long)(uint32_t)state * 4164903690ull + (state >> 32);
+                r[k] = (uint32_t)state;
+            }
+            if ((rc = rng_out.alloc(RNG_TABLE))) return rc;
+            HIP_TRY(hipMemcpyAsync(rng_out.p, r.data(), sizeof(uint32_t) * RNG_TABLE, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
         }
         size_t accn = (size_t)B * hg.numangle * hg.numrho;
         if (full && acc_full.n < accn && (rc = acc_full.alloc(accn))) return rc;
@@ -216,7 +230,7 @@ int points_from_bytes(lc_ctx *ctx, int *npoints_host) {
     hipStream_t st = ctx->stream;
     launch_pack_nonzero(ctx->tmpA.p, w.g, 1, w.rowplane.p, w.rowcount.p, st);
     launch_rowscan(w.g, 1, w.rowcount.p, w.rowoff.p, w.npoints.p, st);
-    launch_scatter(w.g, 1, w.rowplane.p, w.rowoff.p, w.nz.p, w.nz_cap, st);
+    launch_scatter(w.g, 1, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, st);
     if (npoints_host) {
         HIP_TRY(hipMemcpyAsync(npoints_host, w.npoints.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -529,10 +543,10 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
     const int na = wk.hg.numangle, nr = wk.hg.numrho;
     if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
     if ((rc = points_from_bytes(ctx, nullptr))) return rc;
-    HIP_TRY(hipMemsetAsync(wk.acc_ppht.p, 0, sizeof(int32_t) * (size_t)na * nr, ctx->stream));
     HIP_TRY(hipMemsetAsync(wk.status.p, 0, sizeof(int), ctx->stream));
     launch_ppht(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, wk.acc_ppht.p, threshold,
-                (int)lrint(min_line_length), (int)lrint(max_line_gap), wk.seg.p, cap, wk.segcount.p, wk.status.p, ctx->stream);
+                (int)lrint(min_line_length), (int)lrint(max_line_gap), wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p,
+                wk.rng_out.p, RNG_TABLE, ctx->stream);
     int host[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&host[0], wk.segcount.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&host[1], wk.status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -591,17 +605,17 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     const bool hough = p.want_accumulator || p.want_segments;
     if (hough) {
         launch_rowscan(w.g, n, w.rowcount.p, w.rowoff.p, w.npoints.p, s.st);
-        launch_scatter(w.g, n, w.rowplane.p, w.rowoff.p, w.nz.p, w.nz_cap, s.st);
+        launch_scatter(w.g, n, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, s.st);
     }
     (void)hipEventRecord(s.ev[EV_POINTS], s.st);
     if (p.want_accumulator)
         launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, s.st);
     (void)hipEventRecord(s.ev[EV_VOTE], s.st);
     if (p.want_segments) {
-        (void)hipMemsetAsync(w.acc_ppht.p, 0, sizeof(int32_t) * (size_t)n * w.hg.numangle * w.hg.numrho, s.st);
         (void)hipMemsetAsync(w.status.p, 0, sizeof(int), s.st);
         launch_ppht(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
-                    p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p, s.st);
+                    p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p, w.fallback.p,
+                    w.rng_out.p, RNG_TABLE, s.st);
     }
     (void)hipEventRecord(s.ev[EV_LINES], s.st);
     if (p.want_segments) {

@@ -8,6 +8,7 @@
 // and __float2int_rn.  The trig table and the walk steps come from the host.
 #include "common.h"
 #include <climits>
+#include <algorithm>
 
 namespace lanecv {
 namespace {
@@ -41,23 +42,36 @@ __global__ __launch_bounds__(256) void k_rowscan(int H, const int *__restrict__ 
     if (tid == 255) npoints[f] = part[255];
 }
 
-// one wavefront per (frame, row): points in left-to-right order at the row's offset
+// one wavefront per (frame, row): points in left-to-right order at the row's offset.  Empty rows
+// (most of the image outside the ROI) leave at once; otherwise lane l takes word l of the row, a
+// wave scan of the popcounts places each word's points.
 __global__ __launch_bounds__(256) void k_scatter(Geo g, int nframes, const uint64_t *__restrict__ rowplane,
-                                                 const int *__restrict__ rowoff, uint32_t *__restrict__ nz, int nz_cap) {
+                                                 const int *__restrict__ rowcount, const int *__restrict__ rowoff,
+                                                 uint32_t *__restrict__ nz, int nz_cap) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long long)nframes * g.H) return;
+    if (rowcount[row] == 0) return;
     const int f = (int)(row / g.H), y = (int)(row % g.H);
     int off = rowoff[row];
     uint32_t *out = nz + (size_t)f * nz_cap;
-    for (int tx = 0; tx < g.TX; tx++) {
-        uint64_t w = rowplane[(size_t)row * g.TX + tx];
-        if (w == 0) continue;
-        if ((w >> lane) & 1) {
-            int pos = off + __popcll(w & ((1ull << lane) - 1));
-            if (pos < nz_cap) out[pos] = (uint32_t)(tx * 64 + lane) | ((uint32_t)y << 16);
+    for (int tx0 = 0; tx0 < g.TX; tx0 += 64) {
+        const int tx = tx0 + lane;
+        uint64_t w = tx < g.TX ? rowplane[(size_t)row * g.TX + tx] : 0;
+        const int c = __popcll(w);
+        int incl = c;   // inclusive scan over the lanes
+        for (int d = 1; d < 64; d <<= 1) {
+            int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
         }
-        off += __popcll(w);
+        int pos = off + incl - c;
+        while (w) {
+            int b = __builtin_ctzll(w);
+            if (pos < nz_cap) out[pos] = (uint32_t)(tx * 64 + b) | ((uint32_t)y << 16);
+            pos++;
+            w &= w - 1;
+        }
+        off += __shfl(incl, 63);
     }
 }
 
@@ -111,6 +125,18 @@ __device__ __forceinline__ long long shfl_xor_i64(long long v, int m) {
     return ((long long)hi << 32) | (unsigned)lo;
 }
 
+// maximum of a signed 32-bit key over the wavefront, returned wave-uniform: two quad permutes and two
+// row rotates (DPP, no LDS traffic) leave each row of 16 lanes with its maximum, four readlanes finish.
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));   // row_ror:4
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));   // row_ror:8
+    int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
 struct Walk {
     int xflag, x0, y0, dx, dy;   // fixed-point start and step of direction 0
     __device__ __forceinline__ void at(int t, int sgn, int &j1, int &i1) const {
@@ -120,24 +146,139 @@ struct Walk {
     }
 };
 
-__global__ __launch_bounds__(64) void k_ppht(Geo g, uint32_t *__restrict__ nz_all, int nz_cap,
-                                             const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
-                                             const AngleEntry *__restrict__ tab, int numangle, int numrho,
-                                             int32_t *__restrict__ acc_all, int threshold, int line_length, int line_gap,
-                                             int32_t *__restrict__ seg_all, int seg_cap, int *__restrict__ seg_count,
-                                             int *__restrict__ status) {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const int W = g.W, H = g.H, TX = g.TX;
+#ifdef LC_STAMPS
+__device__ long long g_stamps[8];   // diagnostic build only: cycle sums of frame 0
+#define STAMP() __builtin_amdgcn_s_memtime()
+#endif
+constexpr int LDS_BIAS = 0x4000;   // offset of the 16-bit accumulator bins kept in LDS
+
+// Per-frame constants of one HoughLinesP run.
+struct Ppht {
+    int W, H, TX, numangle, numrho, half, threshold, line_length, line_gap, seg_cap;
+    uint64_t *mask;            // row-major bit plane of the frame (bits are cleared as lines are found)
+    const AngleEntry *tab;
+    int16_t *lacc;             // LDS accumulator (fast path)
+    int32_t *acc;              // global accumulator (general path)
+    int32_t *seg;
+};
+
+// A point reached the threshold at angle max_n: walk the line both ways, decide whether it is long
+// enough, clear its mask bits and, if accepted, take its votes back and emit the segment.
+// (The constants travel by value and the per-lane trig pair in registers: a struct behind a reference
+// would be re-read from scratch memory after every atomic, a table in memory after every iteration.)
+// Returns true when the line was accepted (segment number nseg written if it fits).
+template <bool LDS_STATE>
+__device__ __noinline__ bool extract_line(const Ppht c, int lane, int j, int i, int max_n, int nseg, float my_c, float my_s) {
+    const AngleEntry e = c.tab[max_n];
+    Walk wk;
+    wk.xflag = e.xflag;
+    if (e.xflag) { wk.x0 = j; wk.y0 = (i << 16) + 32768; wk.dx = e.dmaj; wk.dy = e.dmin; }
+    else         { wk.x0 = (j << 16) + 32768; wk.y0 = i; wk.dx = e.dmin; wk.dy = e.dmaj; }
+
+    // pass 1: how far the line reaches in each direction
+    int end_t[2];
+    for (int k = 0; k < 2; k++) {
+        const int sgn = k ? -1 : 1;
+        int last_t = 0;
+        for (int base = 0;; base += 64) {
+            int j1, i1;
+            wk.at(base + lane, sgn, j1, i1);
+            const bool inb = (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
+            bool bit = false;
+            if (inb) bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
+            const uint64_t inb_m = __ballot(inb);
+            uint64_t nz_m = __ballot(bit);
+            const int first_oob = inb_m == ~0ull ? 64 : __builtin_ctzll(~inb_m);
+            if (first_oob < 64) nz_m &= (1ull << first_oob) - 1;
+            bool done = false;
+            while (nz_m) {
+                int tt = base + __builtin_ctzll(nz_m);
+                if (tt > last_t + c.line_gap + 1) { done = true; break; }
+                last_t = tt;
+                nz_m &= nz_m - 1;
+            }
+            if (done || first_oob < 64 || base + 63 - last_t > c.line_gap) break;
+        }
+        end_t[k] = last_t;
+    }
+    int ex0, ey0, ex1, ey1;
+    wk.at(end_t[0], 1, ex0, ey0);
+    wk.at(end_t[1], -1, ex1, ey1);
+    const bool good = abs(ex1 - ex0) >= c.line_length || abs(ey1 - ey0) >= c.line_length;
+
+    // pass 2: clear the mask along the line; an accepted line takes its votes back
+    for (int k = 0; k < 2; k++) {
+        const int sgn = k ? -1 : 1;
+        for (int base = k; base <= end_t[k]; base += 64) {   // t = 0 is handled by direction 0
+            const int t = base + lane;
+            bool bit = false;
+            int j1 = 0, i1 = 0;
+            if (t <= end_t[k]) {
+                wk.at(t, sgn, j1, i1);
+                bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
+            }
+            if constexpr (LDS_STATE) {
+                // lane = pixel, loop over the angles.  Two pixels may share a bin, so the decrement is an
+                // LDS atomic on the 32-bit word that holds two biased 16-bit bins; the bias keeps either
+                // half from borrowing out of the other.
+                if (bit && good) {
+                    uint32_t *words = reinterpret_cast<uint32_t *>(c.lacc);
+                    for (int nn = 0; nn < c.numangle; nn++) {   // at most 64 angles here: lane nn holds angle nn's pair
+                        const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_c), nn));
+                        const float ss = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_s), nn));
+                        int r = rho_bin(j1, i1, cc, ss, c.half);
+                        if ((unsigned)r < (unsigned)c.numrho) {
+                            int a = nn * c.numrho + r;
+                            atomicSub(&words[a >> 1], (a & 1) ? 0x10000u : 1u);
+                        }
+                    }
+                }
+            } else if (bit && good) {
+                for (int nn = 0; nn < c.numangle; nn++) {
+                    int r = rho_bin(j1, i1, c.tab[nn].c, c.tab[nn].s, c.half);
+                    if ((unsigned)r < (unsigned)c.numrho) atomicSub(&c.acc[(size_t)nn * c.numrho + r], 1);
+                }
+            }
+            if (bit) atomicAnd((unsigned long long *)(c.mask + (size_t)i1 * c.TX + (j1 >> 6)), ~(1ull << (j1 & 63)));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (good && lane == 0 && nseg < c.seg_cap) {
+        c.seg[4 * nseg + 0] = ex0; c.seg[4 * nseg + 1] = ey0;
+        c.seg[4 * nseg + 2] = ex1; c.seg[4 * nseg + 3] = ey1;
+    }
+    return good;
+}
+
+// General path: every piece of state in global memory behind agent-scope atomics, any number of
+// angles and points.  After the fast path it only runs the frames that path flagged.
+__global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restrict__ nz_all, int nz_cap,
+                                                      const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
+                                                      const AngleEntry *__restrict__ tab, int numangle, int numrho,
+                                                      int32_t *__restrict__ acc_all, int threshold, int line_length,
+                                                      int line_gap, int32_t *__restrict__ seg_all, int seg_cap,
+                                                      int *__restrict__ seg_count, int *__restrict__ status,
+                                                      const int *__restrict__ fallback) {
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (fallback && !fallback[f]) return;
     uint32_t *nz = nz_all + (size_t)f * nz_cap;
-    uint64_t *mask = rowplane + (size_t)f * g.rowplane_words();
-    int32_t *acc = acc_all + (size_t)f * numangle * numrho;
-    int32_t *seg = seg_all + (size_t)f * seg_cap * 4;
-    const int half = (numrho - 1) / 2;
-    int n = npoints[f];
+    Ppht c;
+    c.W = g.W; c.H = g.H; c.TX = g.TX; c.numangle = numangle; c.numrho = numrho; c.half = (numrho - 1) / 2;
+    c.threshold = threshold; c.line_length = line_length; c.line_gap = line_gap; c.seg_cap = seg_cap;
+    c.mask = rowplane + (size_t)f * g.rowplane_words();
+    c.tab = tab; c.lacc = nullptr;
+    c.acc = acc_all + (size_t)f * numangle * numrho;
+    c.seg = seg_all + (size_t)f * seg_cap * 4;
+    const int n = npoints[f];
     if (n > nz_cap) {   // the point list was truncated: refuse rather than differ
-        if (lane == 0) { seg_count[f] = 0; atomicOr(status, 1); }
+        if (tid == 0) { seg_count[f] = 0; atomicOr(status, 1); }
         return;
     }
+    for (int i = tid; i < numangle * numrho; i += 256) c.acc[i] = 0;
+    __threadfence();
+    __syncthreads();
+    if (tid >= 64) return;
+
     unsigned long long state = 0xFFFFFFFFFFFFFFFFull;
     int nseg = 0;
     for (int count = n; count > 0; count--) {
@@ -147,15 +288,14 @@ __global__ __launch_bounds__(64) void k_ppht(Geo g, uint32_t *__restrict__ nz_al
         const uint32_t last = ld_l2(nz + count - 1);
         if (lane == 0) st_l2(nz + idx, last);
         const int j = pt & 0xFFFF, i = pt >> 16;
-        const uint64_t mw = ld_l2(mask + (size_t)i * TX + (j >> 6));
+        const uint64_t mw = ld_l2(c.mask + (size_t)i * c.TX + (j >> 6));
         if (!((mw >> (j & 63)) & 1)) continue;
-
-        // vote; key orders by count first, then by smaller angle index
+        // vote; the key orders by count first, then by smaller angle index
         long long best = LLONG_MIN;
         for (int nn = lane; nn < numangle; nn += 64) {
-            int r = rho_bin(j, i, tab[nn].c, tab[nn].s, half);
+            int r = rho_bin(j, i, tab[nn].c, tab[nn].s, c.half);
             if ((unsigned)r >= (unsigned)numrho) { atomicOr(status, 2); continue; }
-            int val = atomicAdd(&acc[(size_t)nn * numrho + r], 1) + 1;
+            int val = atomicAdd(&c.acc[(size_t)nn * numrho + r], 1) + 1;
             long long key = (long long)val * 4294967296ll + (long long)(0x7FFFFFFF - nn);
             best = key > best ? key : best;
         }
@@ -167,76 +307,195 @@ __global__ __launch_bounds__(64) void k_ppht(Geo g, uint32_t *__restrict__ nz_al
         const int max_n = 0x7FFFFFFF - (int)(unsigned)(best & 0xFFFFFFFFll);
         const int max_val = (int)((best - (long long)(0x7FFFFFFF - max_n)) / 4294967296ll);
         if (max_val < threshold) continue;
-
-        const AngleEntry e = tab[max_n];
-        Walk wk;
-        wk.xflag = e.xflag;
-        if (e.xflag) { wk.x0 = j; wk.y0 = (i << 16) + 32768; wk.dx = e.dmaj; wk.dy = e.dmin; }
-        else         { wk.x0 = (j << 16) + 32768; wk.y0 = i; wk.dx = e.dmin; wk.dy = e.dmaj; }
-
-        // pass 1: how far the line reaches in each direction
-        int end_t[2];
-        for (int k = 0; k < 2; k++) {
-            const int sgn = k ? -1 : 1;
-            int last_t = 0;
-            for (int base = 0;; base += 64) {
-                int j1, i1;
-                wk.at(base + lane, sgn, j1, i1);
-                const bool inb = (unsigned)j1 < (unsigned)W && (unsigned)i1 < (unsigned)H;
-                bool bit = false;
-                if (inb) bit = (ld_l2(mask + (size_t)i1 * TX + (j1 >> 6)) >> (j1 & 63)) & 1;
-                const uint64_t inb_m = __ballot(inb);
-                uint64_t nz_m = __ballot(bit);
-                const int first_oob = inb_m == ~0ull ? 64 : __builtin_ctzll(~inb_m);
-                if (first_oob < 64) nz_m &= (1ull << first_oob) - 1;
-                bool done = false;
-                while (nz_m) {
-                    int tt = base + __builtin_ctzll(nz_m);
-                    if (tt > last_t + line_gap + 1) { done = true; break; }
-                    last_t = tt;
-                    nz_m &= nz_m - 1;
-                }
-                if (done || first_oob < 64 || base + 63 - last_t > line_gap) break;
-            }
-            end_t[k] = last_t;
-        }
-        int ex0, ey0, ex1, ey1;
-        wk.at(end_t[0], 1, ex0, ey0);
-        wk.at(end_t[1], -1, ex1, ey1);
-        const bool good = abs(ex1 - ex0) >= line_length || abs(ey1 - ey0) >= line_length;
-
-        // pass 2: clear the mask along the line; an accepted line takes its votes back
-        for (int k = 0; k < 2; k++) {
-            const int sgn = k ? -1 : 1;
-            for (int base = k; base <= end_t[k]; base += 64) {   // t = 0 is handled by direction 0
-                const int t = base + lane;
-                bool bit = false;
-                int j1 = 0, i1 = 0;
-                if (t <= end_t[k]) {
-                    wk.at(t, sgn, j1, i1);
-                    bit = (ld_l2(mask + (size_t)i1 * TX + (j1 >> 6)) >> (j1 & 63)) & 1;
-                }
-                if (bit) {
-                    if (good) {
-                        for (int nn = 0; nn < numangle; nn++) {
-                            int r = rho_bin(j1, i1, tab[nn].c, tab[nn].s, half);
-                            if ((unsigned)r < (unsigned)numrho) atomicSub(&acc[(size_t)nn * numrho + r], 1);
-                        }
-                    }
-                    atomicAnd((unsigned long long *)(mask + (size_t)i1 * TX + (j1 >> 6)), ~(1ull << (j1 & 63)));
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (good) {
-            if (lane == 0 && nseg < seg_cap) {
-                seg[4 * nseg + 0] = ex0; seg[4 * nseg + 1] = ey0;
-                seg[4 * nseg + 2] = ex1; seg[4 * nseg + 3] = ey1;
-            }
-            nseg++;
-        }
+        if (extract_line<false>(c, lane, j, i, max_n, nseg, 0.f, 0.f)) nseg++;
     }
     if (lane == 0) seg_count[f] = nseg;
+}
+
+// Fast path (up to 64 angles, point list and int16 accumulator fit the CU's LDS):
+//   wavefront 1 runs the data-independent part of OpenCV's loop -- the MWC random picks with
+//   swap-remove -- ahead of time, leaving the visiting order in the point array itself (the removed
+//   point goes to the slot the swap frees, so the array read from the back is the order);
+//   wavefront 0 follows it, with the mask words of the next four points in flight, votes in LDS with
+//   one angle per lane and reduces the maximum with DPP.
+__global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__restrict__ nz_all, int nz_cap,
+                                                   const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
+                                                   const AngleEntry *__restrict__ tab, int numangle, int numrho,
+                                                   int threshold, int line_length, int line_gap,
+                                                   int32_t *__restrict__ seg_all, int seg_cap, int *__restrict__ seg_count,
+                                                   int *__restrict__ status, int *__restrict__ fallback, int lds_points,
+                                                   const uint32_t *__restrict__ rng_out) {
+    extern __shared__ int16_t lds16[];
+    __shared__ int progress;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *nz = nz_all + (size_t)f * nz_cap;
+    const int n = npoints[f];
+    if (n > nz_cap) {
+        if (tid == 0) { seg_count[f] = 0; fallback[f] = 0; atomicOr(status, 1); }
+        return;
+    }
+    if (n > lds_points || n >= LDS_BIAS) {   // biased 16-bit bins hold counts in (-LDS_BIAS, LDS_BIAS)
+        if (tid == 0) fallback[f] = 1;
+        return;
+    }
+    Ppht c;
+    c.W = g.W; c.H = g.H; c.TX = g.TX; c.numangle = numangle; c.numrho = numrho; c.half = (numrho - 1) / 2;
+    c.threshold = threshold; c.line_length = line_length; c.line_gap = line_gap; c.seg_cap = seg_cap;
+    c.mask = rowplane + (size_t)f * g.rowplane_words();
+    c.tab = tab; c.acc = nullptr;
+    c.lacc = lds16;
+    c.seg = seg_all + (size_t)f * seg_cap * 4;
+    uint32_t *lnz = reinterpret_cast<uint32_t *>(lds16 + (((size_t)numangle * numrho + 1) & ~(size_t)1));
+    {
+        uint32_t *z = reinterpret_cast<uint32_t *>(lds16);
+        const int zw = (numangle * numrho + 1) / 2;
+        for (int i = tid; i < zw; i += 256) z[i] = (uint32_t)LDS_BIAS * 0x10001u;
+        for (int i = tid; i < n; i += 256) lnz[i] = nz[i];
+        if (tid == 0) { progress = 0; fallback[f] = 0; }
+    }
+    __syncthreads();
+    if (wave >= 2) return;
+
+    if (wave == 1) {   // producer: visiting order, in place
+#ifdef LC_STAMPS
+        long long tp0 = STAMP();
+#endif
+        // rng_out[k] is the k-th output of cv::RNG(2^64 - 1) (fixed seed, so a host-made table);
+        // 64 lanes reduce 64 picks modulo their counts at once, the swap-removes then run in order
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            uint32_t idxv = 0;
+            if (k < n) idxv = rng_out[k] % (uint32_t)(n - k);
+            const int m = min(64, n - k0);
+            for (int t = 0; t < m; t++) {
+                const uint32_t idx = __shfl(idxv, t);
+                const int cnt = n - (k0 + t);
+                if (lane == 0) {
+                    const uint32_t pt = lnz[idx], last = lnz[cnt - 1];
+                    lnz[idx] = last;
+                    lnz[cnt - 1] = pt;
+                }
+            }
+            if (lane == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                *(volatile int *)&progress = k0 + m;
+            }
+        }
+#ifdef LC_STAMPS
+        if (f == 0 && lane == 0) g_stamps[0] = STAMP() - tp0;
+#endif
+        return;
+    }
+
+    // consumer.  Points are taken 64 at a time: lane t loads point k + t and its mask word, a ballot
+    // says which are still alive (dead ones cost nothing).  Alive points vote four at a time with
+    // returning LDS atomics issued back to back; if one of them reaches the threshold the votes of the
+    // later ones are taken back, the line is extracted and the batch restarts behind that point, so
+    // every count any point sees is the one OpenCV's strictly sequential loop would see.
+    float my_c = 0.f, my_s = 0.f;
+    if (lane < numangle) { my_c = tab[lane].c; my_s = tab[lane].s; }
+    uint32_t *words = reinterpret_cast<uint32_t *>(c.lacc);
+    int nseg = 0;
+#ifdef LC_STAMPS
+    long long t_wait = 0, t_vote = 0, t_line = 0, n_alive = 0, n_line = 0, tc0 = STAMP();
+#endif
+    int k = 0;
+    while (k < n) {
+        const int m = min(64, n - k);
+#ifdef LC_STAMPS
+        long long tw = STAMP();
+#endif
+        while (*(volatile int *)&progress < k + m) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint32_t ptv = 0;
+        bool alive_l = false;
+        if (lane < m) {
+            ptv = lnz[n - 1 - (k + lane)];
+            const uint64_t w = ld_l2(c.mask + (size_t)(ptv >> 16) * c.TX + ((ptv & 0xFFFF) >> 6));
+            alive_l = (w >> (ptv & 63)) & 1;
+        }
+        uint64_t alive = __ballot(alive_l);
+#ifdef LC_STAMPS
+        t_wait += STAMP() - tw;
+#endif
+        bool restarted = false;
+        while (alive && !restarted) {
+            constexpr int Q = 4;
+            int tq[Q], pj[Q], pi[Q], key[Q];
+            uint32_t inc[Q], widx[Q];
+#ifdef LC_STAMPS
+            long long tv = STAMP();
+#endif
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                tq[q] = -1; key[q] = INT_MIN; inc[q] = 0; widx[q] = 0; pj[q] = pi[q] = 0;
+                if (alive) {
+                    tq[q] = __builtin_ctzll(alive);
+                    alive &= alive - 1;
+                    const uint32_t pt = (uint32_t)__builtin_amdgcn_readlane((int)ptv, tq[q]);
+                    pj[q] = pt & 0xFFFF; pi[q] = pt >> 16;
+                }
+            }
+            uint32_t old[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                old[q] = 0;
+                if (tq[q] >= 0 && lane < numangle) {
+                    const int r = rho_bin(pj[q], pi[q], my_c, my_s, c.half);
+                    if ((unsigned)r >= (unsigned)numrho) atomicOr(status, 2);
+                    else {
+                        const int a = lane * numrho + r;
+                        widx[q] = a >> 1;
+                        inc[q] = (a & 1) ? 0x10000u : 1u;
+                        old[q] = atomicAdd(&words[widx[q]], inc[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                if (inc[q]) {
+                    const int raw = (int)((inc[q] == 1u ? old[q] : (old[q] >> 16)) & 0xFFFFu) + 1;
+                    key[q] = (raw - LDS_BIAS) * 64 + (63 - lane);   // count first, then the smaller angle index
+                }
+                key[q] = wave_max_i32(key[q]);
+            }
+#ifdef LC_STAMPS
+            t_vote += STAMP() - tv;
+#endif
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                if (restarted || tq[q] < 0 || key[q] == INT_MIN) continue;
+#ifdef LC_STAMPS
+                n_alive++;
+#endif
+                const int max_n = 63 - (key[q] & 63);
+                const int max_val = (key[q] - (63 - max_n)) / 64;
+                if (max_val < threshold) continue;
+                // point q starts a line: points behind it have not voted yet in OpenCV's order
+#pragma unroll
+                for (int e = q + 1; e < Q; e++)
+                    if (inc[e]) atomicSub(&words[widx[e]], inc[e]);
+#ifdef LC_STAMPS
+                long long tl = STAMP();
+                n_line++;
+#endif
+                if (extract_line<true>(c, lane, pj[q], pi[q], max_n, nseg, my_c, my_s)) nseg++;
+#ifdef LC_STAMPS
+                t_line += STAMP() - tl;
+#endif
+                k += tq[q] + 1;
+                restarted = true;
+            }
+        }
+        if (!restarted) k += m;
+    }
+    if (lane == 0) seg_count[f] = nseg;
+#ifdef LC_STAMPS
+    if (f == 0 && lane == 0) {
+        g_stamps[1] = STAMP() - tc0; g_stamps[2] = t_wait; g_stamps[3] = t_vote; g_stamps[4] = t_line;
+        g_stamps[5] = n_alive; g_stamps[6] = n_line; g_stamps[7] = n;
+    }
+#endif
 }
 
 }  // namespace
@@ -245,10 +504,11 @@ void launch_rowscan(Geo g, int nframes, const int *rowcount, int *rowoff, int *n
     hipLaunchKernelGGL(k_rowscan, dim3(nframes), dim3(256), 0, st, g.H, rowcount, rowoff, npoints);
 }
 
-void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, const int *rowoff, uint32_t *nz, int nz_cap,
-                    hipStream_t st) {
+void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, const int *rowcount, const int *rowoff, uint32_t *nz,
+                    int nz_cap, hipStream_t st) {
     long long rows = (long long)nframes * g.H;
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, g, nframes, rowplane, rowoff, nz, nz_cap);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, g, nframes, rowplane, rowcount, rowoff, nz,
+                       nz_cap);
 }
 
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
@@ -267,9 +527,28 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
 
 void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                  const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
-                 int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, hipStream_t st) {
-    hipLaunchKernelGGL(k_ppht, dim3(nframes), dim3(64), 0, st, g, nz, nz_cap, npoints, rowplane, tab, numangle, numrho, acc,
-                       threshold, line_length, line_gap, seg, seg_cap, seg_count, status);
+                 int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, int *fallback,
+                 const uint32_t *rng_out, int rng_len, hipStream_t st) {
+    // fast path: int16 accumulator + point list in LDS (160 KiB per CU); frames that do not fit fall back
+    const size_t acc_bytes = (((size_t)numangle * numrho + 1) & ~(size_t)1) * 2;
+    const size_t lds_max = 160 * 1024 - 512;
+    bool fast = false;
+    if (numangle <= 64 && acc_bytes + 4096 <= lds_max) {
+        const int lds_points = std::min((int)((lds_max - acc_bytes) / 4), rng_len);
+        const size_t lds = acc_bytes + 4 * (size_t)lds_points;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(256), lds, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+                           numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, fallback, lds_points, rng_out);
+        fast = true;
+    }
+    hipLaunchKernelGGL(k_ppht_general, dim3(nframes), dim3(256), 0, st, g, nz, nz_cap, npoints, rowplane, tab, numangle, numrho,
+                       acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, fast ? fallback : nullptr);
 }
+
+#ifdef LC_STAMPS
+extern "C" int lc_debug_stamps(long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 8);
+}
+#endif
 
 }  // namespace lanecv
