@@ -683,7 +683,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     pp->line_length = (int)lrint(p.min_line_length);
     pp->line_gap = (int)lrint(p.max_line_gap);
 
-    // ROI and car mask fold into one tile-major bit plane: keep = (roi == 255) && (car != 0)
+    // ROI and car mask fold into one bit plane: keep = (roi == 255) && (car != 0)
     if (p.roi_mask || p.car_mask) {
         const Geo g = pp->g;
         std::vector<uint64_t> bits(g.plane_words(), 0);
@@ -700,7 +700,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
                     keep = v != 0;
                 }
                 if (keep && p.car_mask) keep = p.car_mask[i] != 0;
-                if (keep) bits[((size_t)(y >> 6) * g.TX + (x >> 6)) * TILE + (y & 63)] |= 1ull << (x & 63);
+                if (keep) bits[(size_t)y * g.TX + (x >> 6)] |= 1ull << (x & 63);
             }
         if ((rc = pp->roi_bits.alloc(bits.size()))) { delete pp; return rc; }
         hipError_t e = hipMemcpy(pp->roi_bits.p, bits.data(), bits.size() * 8, hipMemcpyHostToDevice);

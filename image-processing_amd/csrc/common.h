@@ -9,17 +9,16 @@ namespace lanecv {
 // ---- geometry of the bit-plane representation ------------------------------
 // The Canny classification and the final edge map live in HBM as bit planes,
 // one uint64 per 64 consecutive pixels of a row.
-//   tile-major plane  P[frame][ty][tx][row 0..63]   (64x64-pixel tiles; used by
-//                     the front kernel's stores and the hysteresis kernel's loads)
-//   row-major plane   M[frame][y][tx]               (used by point compaction and
-//                     the probabilistic Hough kernel)
+// All planes are row-major, P[frame][y][tx] with tx = x / 64 (TX words per row): the strong and
+// weak Canny classes, the ROI mask and the masked edge map the Hough stage consumes.  The
+// hysteresis and finalize kernels work on 64x64-pixel tiles of them (lane = row).
 constexpr int TILE = 64;
 
 struct Geo {
     int W, H;       // pixels
     int TX, TY;     // tiles: ceil(W/64), ceil(H/64)
-    __host__ __device__ size_t plane_words() const { return (size_t)TX * TY * TILE; }   // per frame, tile-major
-    __host__ __device__ size_t rowplane_words() const { return (size_t)TX * H; }        // per frame, row-major
+    __host__ __device__ size_t plane_words() const { return (size_t)TX * H; }      // per frame
+    __host__ __device__ size_t rowplane_words() const { return (size_t)TX * H; }
 };
 
 inline Geo make_geo(int W, int H) {
@@ -40,6 +39,11 @@ struct AngleEntry {
 // ---- launchers (each enqueues on `st`; no synchronisation inside) ----------
 // edge stage
 void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_t *gray, hipStream_t st);
+// streaming front kernel (kernels_front_stream.hip): interleaved 3-channel input, W % 4 == 0
+bool front_stream_supported(Geo g);
+void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
+                         uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, int rows_per_unit,
+                         hipStream_t st);
 void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st);
 // in_kind: 0 = gray bytes in, 1 = interleaved 3-channel bytes in
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes,
@@ -49,7 +53,7 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 // the chains that cross tile borders; rounds[f] receives the closure rounds frame f needed
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint8_t *wake, int *rounds,
                        hipStream_t st);
-// roi_bits: tile-major plane shared by all frames, or nullptr
+// roi_bits: one plane shared by all frames, or nullptr
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits,
                      uint8_t *edges_out, uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st);
 void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t *dst, size_t n, hipStream_t st);

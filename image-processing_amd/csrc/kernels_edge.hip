@@ -10,6 +10,7 @@
 //          asymmetric > / >= comparisons; strict thresholds
 //   hysteresis: 8-connected closure from strong through weak pixels
 #include "common.h"
+#include <cstdlib>
 
 namespace lanecv {
 namespace {
@@ -108,12 +109,8 @@ __global__ __launch_bounds__(FNT) void k_front(const uint8_t *__restrict__ src, 
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * FT_W, ty0 = blockIdx.y * FT_H, f = blockIdx.z;
     const int gx0 = tx0 - HALO, gy0 = ty0 - HALO;
-    const size_t plane_base = ((size_t)(f * g.TY + (ty0 >> 6)) * g.TX + blockIdx.x) * TILE + (ty0 & 63);
-
-    if (ty0 >= H) {   // tile rows that only exist to pad the plane to whole 64-row tiles
-        if (tid < FT_H) { planeS[plane_base + tid] = 0; planeW[plane_base + tid] = 0; }
-        return;
-    }
+    // bit planes are row-major: one word per (row, 64-pixel column group)
+    const size_t plane_base = ((size_t)f * H + ty0) * g.TX + blockIdx.x;
 
     // ---- 1. gray into LDS -------------------------------------------------
     const int cx0 = gx0 < 0 ? 0 : gx0;                       // first in-image column of the region
@@ -245,7 +242,7 @@ __global__ __launch_bounds__(FNT) void k_front(const uint8_t *__restrict__ src, 
             }
         }
         uint64_t bs = __ballot(strong), bw = __ballot(weak);
-        if (c == 0) { planeS[plane_base + r] = bs; planeW[plane_base + r] = bw; }
+        if (c == 0 && y < H) { planeS[plane_base + (size_t)r * g.TX] = bs; planeW[plane_base + (size_t)r * g.TX] = bw; }
     }
 }
 
@@ -283,12 +280,14 @@ __device__ __forceinline__ void stS(uint64_t *p, uint64_t v) {
 // (0 T, 1 B, 2 L, 3 R, 4 TL, 5 TR, 6 BL, 7 BR) that touch a pixel this call made strong.
 __device__ __forceinline__ unsigned hyst_tile(const Geo &g, int f, int ty, int tx, uint64_t *__restrict__ planeS,
                                               const uint64_t *__restrict__ planeW, int lane) {
-    const int tiles_per_frame = g.TX * g.TY;
-    const size_t fb = (size_t)f * tiles_per_frame;
-    const size_t base = (fb + (size_t)ty * g.TX + tx) * TILE;
-    uint64_t Wk = planeW[base + lane];
+    // word of (row y, column group x) of this frame; rows below the image read as empty
+    const size_t fb = (size_t)f * g.H * g.TX;
+    const int y = ty * TILE + lane;
+    const bool yin = y < g.H;
+    auto widx = [&](int yy, int xx) -> size_t { return fb + (size_t)yy * g.TX + xx; };
+    uint64_t Wk = yin ? planeW[widx(y, tx)] : 0;
     if (__ballot(Wk != 0) == 0) return 0;
-    uint64_t S = ldS(planeS + base + lane);
+    uint64_t S = yin ? ldS(planeS + widx(y, tx)) : 0;
     Wk &= ~S;
     if (__ballot(Wk != 0) == 0) return 0;
     const uint64_t S_in = S;
@@ -296,16 +295,17 @@ __device__ __forceinline__ unsigned hyst_tile(const Geo &g, int f, int ty, int t
 
     // strong bits of the one-pixel ring around the tile
     const bool hasL = tx > 0, hasR = tx + 1 < g.TX;
-    uint64_t Lw = hasL ? ldS(planeS + (fb + (size_t)ty * g.TX + tx - 1) * TILE + lane) : 0;
-    uint64_t Rw = hasR ? ldS(planeS + (fb + (size_t)ty * g.TX + tx + 1) * TILE + lane) : 0;
+    uint64_t Lw = (hasL && yin) ? ldS(planeS + widx(y, tx - 1)) : 0;
+    uint64_t Rw = (hasR && yin) ? ldS(planeS + widx(y, tx + 1)) : 0;
     uint64_t lcol = Lw >> 63, rcol = Rw & 1;     // (row, -1) and (row, 64)
     // lanes 0..2: row 63 of tiles (ty-1, tx-1..tx+1); lanes 3..5: row 0 of tiles (ty+1, tx-1..tx+1)
     uint64_t edge = 0;
     if (lane < 6) {
         int dy = lane < 3 ? -1 : 1, dx = (lane % 3) - 1;
         int yy = ty + dy, xx = tx + dx;
-        if (yy >= 0 && yy < g.TY && xx >= 0 && xx < g.TX)
-            edge = ldS(planeS + (fb + (size_t)yy * g.TX + xx) * TILE + (dy < 0 ? 63 : 0));
+        const int ey = dy < 0 ? ty * TILE - 1 : ty * TILE + TILE;
+        if (ey >= 0 && ey < g.H && xx >= 0 && xx < g.TX) edge = ldS(planeS + widx(ey, xx));
+        (void)yy;
     }
     uint64_t tl = shfl_u64(edge, 0) >> 63, tm = shfl_u64(edge, 1), tr = shfl_u64(edge, 2) & 1;
     uint64_t bl = shfl_u64(edge, 3) >> 63, bm = shfl_u64(edge, 4), br = shfl_u64(edge, 5) & 1;
@@ -334,7 +334,7 @@ __device__ __forceinline__ unsigned hyst_tile(const Geo &g, int f, int ty, int t
     const uint64_t added = S & ~S_in;
     const uint64_t any = __ballot(added != 0);
     if (any == 0) return 0;
-    if (added) stS(planeS + base + lane, S);
+    if (added) stS(planeS + widx(y, tx), S);
     const bool top = (any & 1) != 0, bot = (any >> 63) != 0;
     const bool left = __ballot((added & 1) != 0) != 0, right = __ballot((added >> 63) != 0) != 0;
     const uint64_t a0 = shfl_u64(added, 0), a63 = shfl_u64(added, 63);
@@ -434,9 +434,9 @@ __global__ __launch_bounds__(256) void k_finalize(Geo g, int ntiles_total, const
     const int ty = tt / g.TX, tx = tt % g.TX;
     const int W = g.W, H = g.H;
     // lane = row: masked bits, row-major plane and row counts
-    uint64_t S = planeS[(size_t)t * TILE + lane];
-    uint64_t M = roi_bits ? (S & roi_bits[(size_t)tt * TILE + lane]) : S;
     const int yrow = ty * TILE + lane;
+    uint64_t S = yrow < H ? planeS[((size_t)f * H + yrow) * g.TX + tx] : 0;
+    uint64_t M = (roi_bits && yrow < H) ? (S & roi_bits[(size_t)yrow * g.TX + tx]) : S;
     if (yrow < H) {
         if (rowplane) rowplane[((size_t)f * H + yrow) * g.TX + tx] = M;
         if (rowcount) {
@@ -524,8 +524,15 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes, int low,
                   int high, uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, hipStream_t st) {
+    static const char *force_tiled = getenv("LANECV_FRONT_TILED");       // diagnostics: use the tiled kernel everywhere
+    static const char *rows_env = getenv("LANECV_FRONT_ROWS");           // tuning: rows per streaming unit
+    if (in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1')) {
+        launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, gray_out, blur_out,
+                            rows_env ? atoi(rows_env) : 0, st);
+        return;
+    }
     int k0 = code == 6 ? 3735 : 9798, k2 = code == 6 ? 9798 : 3735;
-    dim3 grid(g.TX, g.TY * (TILE / FT_H), nframes), block(FNT);
+    dim3 grid(g.TX, (g.H + FT_H - 1) / FT_H, nframes), block(FNT);
 #define LC_FRONT(B, L) hipLaunchKernelGGL((k_front<B, L>), grid, block, 0, st, src, src_bytes, g, k0, 19235, k2, low, high, planeS, planeW, gray_out, blur_out)
     if (in_kind == 1) { if (blur) LC_FRONT(true, true); else LC_FRONT(true, false); }
     else { if (blur) LC_FRONT(false, true); else LC_FRONT(false, false); }

@@ -134,3 +134,30 @@ def test_full_size_properties():
             assert (masked[i] == masked[j]).all() and (acc[i] == acc[j]).all()
             assert (segs[i] == segs[j]).all()
         pipe.close()
+
+
+@pytest.mark.parametrize("w,h", [(644, 359), (248, 100), (200, 37), (8, 5), (252, 64), (1000, 130), (64, 1), (12, 300)])
+@pytest.mark.parametrize("blur", [False, True])
+def test_streaming_front_sizes(oracle, w, h, blur):
+    """Widths that are multiples of 4 take the streaming front kernel: strips that end inside a
+    64-pixel word, strips wholly outside the image, frames shorter than the vertical halo."""
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    rec = Recipe(color_code=7 if not blur else 6, blur=blur, canny=(40, 90), roi_vertices=None,
+                 segments=False, accumulator=False)
+    pipe = LanePipeline(w, h, rec, max_batch=5, nslots=1, keep_intermediates=True)
+    adv = synth.adversarial_frames(w, h)
+    frames = np.stack([synth.synth_road(w, h, seed=4, t=1), adv["noise"], adv["ramps"], adv["border_impulses"],
+                       adv["checker2"]])
+    pipe.submit(0, frames)
+    pipe.wait(0)
+    gray, edges = pipe.read(0, _abi.BUF_GRAY), pipe.read(0, _abi.BUF_EDGES)
+    bl = pipe.read(0, _abi.BUF_BLUR) if blur else None
+    for i, f in enumerate(frames):
+        g = oracle.cvt_gray(f, rec.color_code)
+        assert (gray[i] == g).all(), i
+        if blur:
+            g = oracle.gaussian5(g)
+            assert (bl[i] == g).all(), i
+        assert (edges[i] == oracle.canny(g, 40, 90)).all(), i
+    pipe.close()
