@@ -93,7 +93,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from lanecv import _abi
+    from lanecv import _abi, shard
     from lanecv.pipeline import LanePipeline, Recipe
     rec = Recipe.north_star(W, H)
     pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=args.slots, seg_capacity=SEG_CAP, device=local_rank)
@@ -135,13 +135,7 @@ def main():
     run(args.steps, stages)
     # final result gather: per-frame segment counts and padded segment lists of the last batch to rank 0
     seg, cnt = results[(args.steps - 1) % args.slots]
-    if world > 1:
-        seg_t = torch.from_numpy(seg).cuda()
-        cnt_t = torch.from_numpy(cnt).cuda()
-        seg_all = [torch.empty_like(seg_t) for _ in range(world)] if rank == 0 else None
-        cnt_all = [torch.empty_like(cnt_t) for _ in range(world)] if rank == 0 else None
-        dist.gather(seg_t, seg_all, dst=0)
-        dist.gather(cnt_t, cnt_all, dst=0)
+    gathered = shard.gather_segments(seg, cnt, dst=0, device="cuda" if world > 1 else None)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -173,7 +167,7 @@ def main():
                          "note": "durations are HIP-event times on the slot's stream inside the timed region, "
                                  "with %d batches in flight on separate streams" % args.slots},
             "stage_ms": {k: round(v, 4) for k, v in mean.items()},
-            "segments_frame0": int(cnt[0]), "hyst_closure_rounds_max_total": list(pipe.hyst_rounds(0)),
+            "segments_frame0": int(cnt[0]), "gathered_ranks": len(gathered), "hyst_closure_rounds_max_total": list(pipe.hyst_rounds(0)),
         }
 
         # exclusive timings: one batch in flight, nothing else on the GPU

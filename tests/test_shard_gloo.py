@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: two gloo ranks shard clips round robin, each produces padded segment lists
+for its clips (here with the CPU oracle standing in for the GPU pipeline, which needs a GPU), and the
+final gather on rank 0 must reproduce the single-process result clip for clip."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, NCLIPS, NFRAMES, CAP = 160, 90, 4, 3, 64
+
+
+def _clip_segments(clip):
+    from lanecv import synth
+    from oracle import lane_oracle as lo
+    roi = np.zeros((H, W), np.uint8)
+    lo.fill_poly(roi, [np.array([(0, H), (W // 2, H // 2), (W, H)])], 255)
+    seg = np.zeros((NFRAMES, CAP, 4), np.int32)
+    cnt = np.zeros(NFRAMES, np.int32)
+    for t in range(NFRAMES):
+        r = lo.lane_frame(synth.synth_road(W, H, 100 + clip, t), 6, True, 50, 150, roi, 6, np.pi / 60, 20, 10, 5,
+                          want_acc=False)
+        k = len(r["segments"])
+        cnt[t] = k
+        seg[t, :k] = r["segments"][:CAP]
+    return seg, cnt
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "image-processing_amd")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from lanecv import shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    mine = shard.clip_assignment(NCLIPS, world, rank)
+    out = {}
+    for c in mine:
+        seg, cnt = _clip_segments(c)
+        got = shard.gather_segments(seg, cnt, dst=0)
+        if rank == 0:
+            for r, (s, n) in enumerate(got):
+                out[shard.clip_assignment(NCLIPS, world, r)[mine.index(c)]] = (s, n)
+    dist.barrier()
+    if rank == 0:
+        q.put(out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_matches_single_process():
+    for p in (ROOT, os.path.join(ROOT, "image-processing_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from lanecv import shard
+    assert shard.clip_assignment(5, 2, 0) == [0, 2, 4] and shard.clip_assignment(5, 2, 1) == [1, 3]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(out) == list(range(NCLIPS))
+    total = 0
+    for c in range(NCLIPS):
+        seg, cnt = _clip_segments(c)
+        assert (out[c][1] == cnt).all() and (out[c][0] == seg).all()
+        total += int(cnt.sum())
+        assert [len(a) for a in shard.unpad(seg, cnt)] == cnt.tolist()
+    assert total > 0
