@@ -148,6 +148,7 @@ struct Walk {
 
 #ifdef LC_STAMPS
 __device__ long long g_stamps[8];   // diagnostic build only: cycle sums of frame 0
+__device__ unsigned long long g_dbg[4];
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
 constexpr int LDS_BIAS = 0x4000;   // offset of the 16-bit accumulator bins kept in LDS
@@ -162,13 +163,76 @@ struct Ppht {
     int32_t *seg;
 };
 
+// ---- vote removal spread over the wavefronts of the workgroup (fast path) --------------------
+// The line-walking wavefront (wave 0) posts one job per 64-step chunk of an accepted line: the
+// chunk's walk parameters and the ballot of its edge pixels.  Three wavefronts share a job
+// statically -- wave 0 and the two helper waves take angle groups p, p + 3, p + 6, ... -- and
+// subtract the chunk's votes for their angles (lane = pixel).  One job is in flight at a time and
+// every participant reports before the next is posted, so helpers see every job exactly once.
+constexpr int JOB_ANGLES = 5, JOB_WAVES = 3;
+struct Jobs {
+    int seq;                     // jobs posted so far; -1 tells the helpers to leave
+    int done;                    // participants that finished job `seq`
+    int par[16];                 // xflag, x0, y0, dx, dy, sgn, base, bits lo, bits hi
+    float tc[64], ts[64];        // trig table of the (at most 64) angles
+};
+
+__device__ __forceinline__ void job_work(Jobs *jb, int part, const Ppht &c, int lane) {
+    Walk wk;
+    wk.xflag = jb->par[0]; wk.x0 = jb->par[1]; wk.y0 = jb->par[2]; wk.dx = jb->par[3]; wk.dy = jb->par[4];
+    const int sgn = jb->par[5], base = jb->par[6];
+    const uint64_t bits = (uint32_t)jb->par[7] | ((uint64_t)(uint32_t)jb->par[8] << 32);
+    const bool bit = (bits >> lane) & 1;
+    int j1, i1;
+    wk.at(base + lane, sgn, j1, i1);
+    uint32_t *words = reinterpret_cast<uint32_t *>(c.lacc);
+    if (bit) {
+        for (int n0 = part * JOB_ANGLES; n0 < c.numangle; n0 += JOB_WAVES * JOB_ANGLES) {
+            const int n1 = min(c.numangle, n0 + JOB_ANGLES);
+            for (int nn = n0; nn < n1; nn++) {
+                const int r = rho_bin(j1, i1, jb->tc[nn], jb->ts[nn], c.half);
+                if ((unsigned)r < (unsigned)c.numrho) {
+                    const int a = nn * c.numrho + r;
+                    // two biased 16-bit bins per word; the bias keeps a half from borrowing out of the other
+                    atomicSub(&words[a >> 1], (a & 1) ? 0x10000u : 1u);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(&jb->done, 1);
+}
+
+// wave 0: do its share of the job in flight (if any) and wait for the helpers
+__device__ __forceinline__ void job_finish(Jobs *jb, bool inflight, const Ppht &c, int lane) {
+    if (!inflight) return;
+    job_work(jb, 0, c, lane);
+    while (*(volatile int *)&jb->done < JOB_WAVES) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// helper wavefronts (part 1 and 2): serve every job until told to leave
+__device__ __forceinline__ void job_serve(Jobs *jb, int part, const Ppht &c, int lane) {
+    int seen = 0;
+    for (;;) {
+        int sq;
+        while ((sq = *(volatile int *)&jb->seq) == seen) __builtin_amdgcn_s_sleep(2);
+        if (sq < 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        seen = sq;
+        job_work(jb, part, c, lane);
+    }
+}
+
 // A point reached the threshold at angle max_n: walk the line both ways, decide whether it is long
 // enough, clear its mask bits and, if accepted, take its votes back and emit the segment.
-// (The constants travel by value and the per-lane trig pair in registers: a struct behind a reference
-// would be re-read from scratch memory after every atomic, a table in memory after every iteration.)
-// Returns true when the line was accepted (segment number nseg written if it fits).
+// (Inlined at its single call site per kernel so that every LDS access keeps its address space and the
+// constants stay in registers; the per-lane trig pair is read with v_readlane, not from memory.)
+// Returns (accepted ? 1 : 0) | jobs posted so far << 1 (segment number nseg is written if it fits).
+// jobseq is the caller's count of vote-removal jobs posted so far; it lives in registers, not LDS.
 template <bool LDS_STATE>
-__device__ __noinline__ bool extract_line(const Ppht c, int lane, int j, int i, int max_n, int nseg, float my_c, float my_s) {
+__device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int i, int max_n, int nseg, Jobs *jb, int jobseq) {
+    bool inflight = false;   // a vote-removal job of this line is with the helpers
     const AngleEntry e = c.tab[max_n];
     Walk wk;
     wk.xflag = e.xflag;
@@ -218,20 +282,19 @@ __device__ __noinline__ bool extract_line(const Ppht c, int lane, int j, int i, 
                 bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
             }
             if constexpr (LDS_STATE) {
-                // lane = pixel, loop over the angles.  Two pixels may share a bin, so the decrement is an
-                // LDS atomic on the 32-bit word that holds two biased 16-bit bins; the bias keeps either
-                // half from borrowing out of the other.
-                if (bit && good) {
-                    uint32_t *words = reinterpret_cast<uint32_t *>(c.lacc);
-                    for (int nn = 0; nn < c.numangle; nn++) {   // at most 64 angles here: lane nn holds angle nn's pair
-                        const float cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_c), nn));
-                        const float ss = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_s), nn));
-                        int r = rho_bin(j1, i1, cc, ss, c.half);
-                        if ((unsigned)r < (unsigned)c.numrho) {
-                            int a = nn * c.numrho + r;
-                            atomicSub(&words[a >> 1], (a & 1) ? 0x10000u : 1u);
-                        }
+                const uint64_t bm = __ballot(bit);
+                if (good && bm) {   // hand the chunk's vote removal to the workgroup, keep walking
+                    job_finish(jb, inflight, c, lane);       // one job in flight at a time
+                    ++jobseq;
+                    if (lane == 0) {
+                        jb->par[0] = wk.xflag; jb->par[1] = wk.x0; jb->par[2] = wk.y0; jb->par[3] = wk.dx; jb->par[4] = wk.dy;
+                        jb->par[5] = sgn; jb->par[6] = base;
+                        jb->par[7] = (int)(uint32_t)bm; jb->par[8] = (int)(uint32_t)(bm >> 32);
+                        jb->done = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        *(volatile int *)&jb->seq = jobseq;
                     }
+                    inflight = true;
                 }
             } else if (bit && good) {
                 for (int nn = 0; nn < c.numangle; nn++) {
@@ -242,12 +305,13 @@ __device__ __noinline__ bool extract_line(const Ppht c, int lane, int j, int i, 
             if (bit) atomicAnd((unsigned long long *)(c.mask + (size_t)i1 * c.TX + (j1 >> 6)), ~(1ull << (j1 & 63)));
         }
     }
+    if constexpr (LDS_STATE) job_finish(jb, inflight, c, lane);   // every vote is back before the next pick
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (good && lane == 0 && nseg < c.seg_cap) {
         c.seg[4 * nseg + 0] = ex0; c.seg[4 * nseg + 1] = ey0;
         c.seg[4 * nseg + 2] = ex1; c.seg[4 * nseg + 3] = ey1;
     }
-    return good;
+    return (good ? 1 : 0) | (jobseq << 1);
 }
 
 // General path: every piece of state in global memory behind agent-scope atomics, any number of
@@ -307,7 +371,7 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restric
         const int max_n = 0x7FFFFFFF - (int)(unsigned)(best & 0xFFFFFFFFll);
         const int max_val = (int)((best - (long long)(0x7FFFFFFF - max_n)) / 4294967296ll);
         if (max_val < threshold) continue;
-        if (extract_line<false>(c, lane, j, i, max_n, nseg, 0.f, 0.f)) nseg++;
+        if (extract_line<false>(c, lane, j, i, max_n, nseg, nullptr, 0) & 1) nseg++;
     }
     if (lane == 0) seg_count[f] = nseg;
 }
@@ -327,6 +391,7 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
                                                    const uint32_t *__restrict__ rng_out) {
     extern __shared__ int16_t lds16[];
     __shared__ int progress;
+    __shared__ Jobs jobs;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
     const int n = npoints[f];
@@ -351,10 +416,19 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
         const int zw = (numangle * numrho + 1) / 2;
         for (int i = tid; i < zw; i += 256) z[i] = (uint32_t)LDS_BIAS * 0x10001u;
         for (int i = tid; i < n; i += 256) lnz[i] = nz[i];
-        if (tid == 0) { progress = 0; fallback[f] = 0; }
+        if (tid == 0) {
+            progress = 0; fallback[f] = 0;
+            jobs.seq = 0; jobs.done = 0;
+        }
+        if (tid < 64) { jobs.tc[tid] = tid < numangle ? tab[tid].c : 0.f; jobs.ts[tid] = tid < numangle ? tab[tid].s : 0.f; }
     }
     __syncthreads();
-    if (wave >= 2) return;
+    float my_c = 0.f, my_s = 0.f;   // lane l holds the trig pair of angle l
+    if (lane < numangle) { my_c = tab[lane].c; my_s = tab[lane].s; }
+    if (wave >= 2) {                // helpers: vote removal for accepted lines
+        job_serve(&jobs, wave - 1, c, lane);
+        return;
+    }
 
     if (wave == 1) {   // producer: visiting order, in place
 #ifdef LC_STAMPS
@@ -392,10 +466,8 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
     // returning LDS atomics issued back to back; if one of them reaches the threshold the votes of the
     // later ones are taken back, the line is extracted and the batch restarts behind that point, so
     // every count any point sees is the one OpenCV's strictly sequential loop would see.
-    float my_c = 0.f, my_s = 0.f;
-    if (lane < numangle) { my_c = tab[lane].c; my_s = tab[lane].s; }
     uint32_t *words = reinterpret_cast<uint32_t *>(c.lacc);
-    int nseg = 0;
+    int nseg = 0, jobseq = 0;
 #ifdef LC_STAMPS
     long long t_wait = 0, t_vote = 0, t_line = 0, n_alive = 0, n_line = 0, tc0 = STAMP();
 #endif
@@ -451,44 +523,58 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
                     }
                 }
             }
+            // a point starts a line iff some angle's count reaches the threshold: one compare and a ballot
+            // per point; the arg-max over the angles is only needed for the rare point that does
+            uint64_t trig[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                if (inc[q]) {
-                    const int raw = (int)((inc[q] == 1u ? old[q] : (old[q] >> 16)) & 0xFFFFu) + 1;
-                    key[q] = (raw - LDS_BIAS) * 64 + (63 - lane);   // count first, then the smaller angle index
-                }
-                key[q] = wave_max_i32(key[q]);
+                int val = INT_MIN;
+                if (inc[q]) val = (int)((inc[q] == 1u ? old[q] : (old[q] >> 16)) & 0xFFFFu) + 1 - LDS_BIAS;
+                key[q] = val;
+                trig[q] = __ballot(val >= threshold);
             }
 #ifdef LC_STAMPS
             t_vote += STAMP() - tv;
 #endif
+            int hit = -1;   // first point of the batch, in OpenCV's order, that starts a line
 #pragma unroll
-            for (int q = 0; q < Q; q++) {
-                if (restarted || tq[q] < 0 || key[q] == INT_MIN) continue;
+            for (int q = Q - 1; q >= 0; q--)
+                if (tq[q] >= 0 && trig[q] != 0) hit = q;
 #ifdef LC_STAMPS
-                n_alive++;
-#endif
-                const int max_n = 63 - (key[q] & 63);
-                const int max_val = (key[q] - (63 - max_n)) / 64;
-                if (max_val < threshold) continue;
-                // point q starts a line: points behind it have not voted yet in OpenCV's order
 #pragma unroll
-                for (int e = q + 1; e < Q; e++)
-                    if (inc[e]) atomicSub(&words[widx[e]], inc[e]);
+            for (int q = 0; q < Q; q++) n_alive += (tq[q] >= 0 && (hit < 0 || q <= hit)) ? 1 : 0;
+#endif
+            if (hit >= 0) {
+                int hkey = key[0], hj = pj[0], hi = pi[0], ht = tq[0];
+#pragma unroll
+                for (int q = 1; q < Q; q++)
+                    if (hit == q) { hkey = key[q]; hj = pj[q]; hi = pi[q]; ht = tq[q]; }
+                // count first, then the smaller angle index (OpenCV keeps the first maximum)
+                const int kmax = wave_max_i32(hkey == INT_MIN ? INT_MIN : hkey * 64 + (63 - lane));
+                const int max_n = 63 - (kmax & 63);
+                // the points behind it have not voted yet in OpenCV's order: take their votes back
+#pragma unroll
+                for (int e = 1; e < Q; e++)
+                    if (e > hit && inc[e]) atomicSub(&words[widx[e]], inc[e]);
 #ifdef LC_STAMPS
                 long long tl = STAMP();
                 n_line++;
 #endif
-                if (extract_line<true>(c, lane, pj[q], pi[q], max_n, nseg, my_c, my_s)) nseg++;
+                const int lr = extract_line<true>(c, lane, hj, hi, max_n, nseg, &jobs, jobseq);
+                jobseq = lr >> 1;
+                if (lr & 1) nseg++;
 #ifdef LC_STAMPS
                 t_line += STAMP() - tl;
 #endif
-                k += tq[q] + 1;
+                k += ht + 1;
                 restarted = true;
             }
         }
         if (!restarted) k += m;
     }
+#ifdef LC_STAMPS
+#endif
+    if (lane == 0) *(volatile int *)&jobs.seq = -1;   // helpers leave
     if (lane == 0) seg_count[f] = nseg;
 #ifdef LC_STAMPS
     if (f == 0 && lane == 0) {
@@ -531,7 +617,7 @@ void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoint
                  const uint32_t *rng_out, int rng_len, hipStream_t st) {
     // fast path: int16 accumulator + point list in LDS (160 KiB per CU); frames that do not fit fall back
     const size_t acc_bytes = (((size_t)numangle * numrho + 1) & ~(size_t)1) * 2;
-    const size_t lds_max = 160 * 1024 - 512;
+    const size_t lds_max = 160 * 1024 - 1024;   // minus the kernel's static LDS (job block, progress word)
     bool fast = false;
     if (numangle <= 64 && acc_bytes + 4096 <= lds_max) {
         const int lds_points = std::min((int)((lds_max - acc_bytes) / 4), rng_len);
@@ -547,6 +633,7 @@ void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoint
 
 #ifdef LC_STAMPS
 extern "C" int lc_debug_stamps(long long *out) {
+    (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_dbg), sizeof(long long) * 4);
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 8);
 }
 #endif

@@ -10,10 +10,10 @@ rec=Recipe.north_star(w,h)
 B=int(sys.argv[1]) if len(sys.argv)>1 else 32
 pipe=LanePipeline(w,h,rec,max_batch=B,nslots=1)
 fr=np.stack([synth.synth_road(w,h,100,t) for t in range(B)])
-for it in range(3):
+for it in range(1):
     pipe.submit(0, fr); pipe.collect(0)
-out=(C.c_longlong*8)()
+out=(C.c_longlong*48)()
 print('rc', _abi.lib().lc_debug_stamps(out))
 names=['producer_cycles','consumer_cycles','wait','vote','line','n_alive','n_line','n']
-print({k:int(v) for k,v in zip(names,out)})
+print({k:int(v) for k,v in zip(names,out)}); print('dbg', list(out)[8:12])
 print('lines ms', pipe.stage_ms(0,_abi.STAGE_LINES))
