@@ -100,7 +100,7 @@ struct Work {
     bool inter = false;
     DevBuf<uint8_t> bgr, gray, blur, edges, masked;
     DevBuf<uint64_t> planeS, planeW, rowplane;
-    DevBuf<uint8_t> wake;
+    DevBuf<uint32_t> wake;        // two wake-flag arrays of B * tiles words (hysteresis closure)
     DevBuf<int> rounds, rowcount, rowoff, npoints, segcount, status, fallback;
     DevBuf<uint32_t> nz;
     int nz_cap = 0;
@@ -127,7 +127,7 @@ struct Work {
         if ((rc = planeS.alloc((size_t)B * g.plane_words()))) return rc;
         if ((rc = planeW.alloc((size_t)B * g.plane_words()))) return rc;
         if ((rc = rowplane.alloc((size_t)B * g.rowplane_words()))) return rc;
-        if ((rc = wake.alloc((size_t)B * g.TX * g.TY))) return rc;
+        if ((rc = wake.alloc(2 * (size_t)B * g.TX * g.TY))) return rc;
         if ((rc = rounds.alloc(B))) return rc;
         if ((rc = rowcount.alloc((size_t)B * H))) return rc;
         if ((rc = rowoff.alloc((size_t)B * H))) return rc;

@@ -51,7 +51,7 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
                   uint8_t *gray_out, uint8_t *blur_out, hipStream_t st);
 // hysteresis to the fixed point: a chip-wide first round, then one workgroup per frame closes
 // the chains that cross tile borders; rounds[f] receives the closure rounds frame f needed
-void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint8_t *wake, int *rounds,
+void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st);
 // roi_bits: one plane shared by all frames, or nullptr
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits,

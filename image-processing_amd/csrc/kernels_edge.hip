@@ -360,7 +360,7 @@ __device__ __forceinline__ int nb_tile(const Geo &g, int ty, int tx, int k) {
 constexpr int HY_WAVES = 4;
 __global__ __launch_bounds__(64 * HY_WAVES) void k_hyst_first(Geo g, int ntiles_total, uint64_t *__restrict__ planeS,
                                                              const uint64_t *__restrict__ planeW,
-                                                             uint8_t *__restrict__ wake) {
+                                                             uint32_t *__restrict__ wake) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * HY_WAVES + (threadIdx.x >> 6);   // global tile index over all frames
     if (t >= ntiles_total) return;
@@ -372,23 +372,27 @@ __global__ __launch_bounds__(64 * HY_WAVES) void k_hyst_first(Geo g, int ntiles_
 }
 
 // closure: one workgroup per frame repeats rounds over the woken tiles until none is woken.
-// All cross-tile hand-offs stay inside the workgroup (barriers + L2-served plane words), so
-// the fixed point is reached on the device with no host round trip.
+// All cross-tile hand-offs stay inside the workgroup (barriers + L2-served words), so the fixed
+// point is reached on the device with no host round trip.  The wake flags live in global memory
+// (two arrays per frame, swapped every round) and the kernel keeps 4 bytes of LDS, so it can share
+// a CU with kernels of other batches that fill the LDS.
 constexpr int HC_THREADS = 1024;
+__device__ __forceinline__ uint32_t ldF(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stF(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ __launch_bounds__(HC_THREADS) void k_hyst_close(Geo g, uint64_t *__restrict__ planeS,
                                                            const uint64_t *__restrict__ planeW,
-                                                           const uint8_t *__restrict__ wake, int *__restrict__ rounds_out) {
-    extern __shared__ uint8_t flags[];   // [2][tiles_per_frame]
+                                                           uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
+                                                           int *__restrict__ rounds_out) {
     __shared__ int any;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = g.TX * g.TY;
-    uint8_t *cur = flags, *nxt = flags + ntile;
+    uint32_t *cur = wakeA + (size_t)f * ntile, *nxt = wakeB + (size_t)f * ntile;   // nxt starts all zero
     int mine = 0;
-    for (int i = tid; i < ntile; i += HC_THREADS) {
-        uint8_t v = wake[(size_t)f * ntile + i];
-        cur[i] = v; nxt[i] = 0;
-        mine |= v;
-    }
+    for (int i = tid; i < ntile; i += HC_THREADS) mine |= (int)cur[i];
     if (tid == 0) any = 0;
     __syncthreads();
     if (mine) any = 1;
@@ -399,13 +403,15 @@ __global__ __launch_bounds__(HC_THREADS) void k_hyst_close(Geo g, uint64_t *__re
         if (tid == 0) any = 0;
         __syncthreads();
         for (int t = wave; t < ntile; t += HC_THREADS / 64) {
-            if (!cur[t]) continue;
+            if (!ldF(cur + t)) continue;
+            if (lane == 0) stF(cur + t, 0);           // this array is next round's target
             const int ty = t / g.TX, tx = t % g.TX;
             const unsigned m = hyst_tile(g, f, ty, tx, planeS, planeW, lane);
-            if (lane < 8 && ((m >> lane) & 1)) { nxt[nb_tile(g, ty, tx, lane)] = 1; any = 1; }
+            if (lane < 8 && ((m >> lane) & 1)) { stF(nxt + nb_tile(g, ty, tx, lane), 1); any = 1; }
         }
+        __threadfence_block();
         __syncthreads();
-        for (int i = tid; i < ntile; i += HC_THREADS) { cur[i] = nxt[i]; nxt[i] = 0; }
+        uint32_t *tmp = cur; cur = nxt; nxt = tmp;
         rounds++;
     }
     if (tid == 0 && rounds_out) rounds_out[f] = rounds;
@@ -539,12 +545,13 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 #undef LC_FRONT
 }
 
-void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint8_t *wake, int *rounds,
+void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st) {
+    // wake holds two flag arrays of nframes * tiles words each
     const int per = g.TX * g.TY, nt = per * nframes;
-    (void)hipMemsetAsync(wake, 0, (size_t)nt, st);
+    (void)hipMemsetAsync(wake, 0, sizeof(uint32_t) * 2 * (size_t)nt, st);
     hipLaunchKernelGGL(k_hyst_first, dim3((nt + HY_WAVES - 1) / HY_WAVES), dim3(64 * HY_WAVES), 0, st, g, nt, planeS, planeW, wake);
-    hipLaunchKernelGGL(k_hyst_close, dim3(nframes), dim3(HC_THREADS), 2 * (size_t)per, st, g, planeS, planeW, wake, rounds);
+    hipLaunchKernelGGL(k_hyst_close, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_scatter(Geo g, int nframes, const uint6
 }
 
 // full-vote accumulator: block (group, frame) owns `apg` angle rows in LDS
-__global__ __launch_bounds__(1024) void k_vote(const uint32_t *__restrict__ nz, int nz_cap, const int *__restrict__ npoints,
+__global__ __launch_bounds__(256) void k_vote(const uint32_t *__restrict__ nz, int nz_cap, const int *__restrict__ npoints,
                                                const AngleEntry *__restrict__ tab, int numangle, int numrho, int apg,
                                                int32_t *__restrict__ acc) {
     extern __shared__ int lacc[];
@@ -239,29 +239,62 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
     if (e.xflag) { wk.x0 = j; wk.y0 = (i << 16) + 32768; wk.dx = e.dmaj; wk.dy = e.dmin; }
     else         { wk.x0 = (j << 16) + 32768; wk.y0 = i; wk.dx = e.dmin; wk.dy = e.dmaj; }
 
+    // The first NC chunks (64 steps each) of both directions are fetched in one go -- all mask words in
+    // flight together, one memory round trip for most lines -- and their ballots are kept: pass 2 needs
+    // the same bits (nothing else clears this line's pixels in between), so it reloads nothing.
+    constexpr int NC = 4;
+    uint64_t nzm[2][NC], inbm[2][NC];
+    {
+        uint64_t wv[2][NC];
+        bool inb[2][NC];
+        int sh[2][NC];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                int j1, i1;
+                wk.at(q * 64 + lane, k ? -1 : 1, j1, i1);
+                inb[k][q] = (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
+                sh[k][q] = j1 & 63;
+                wv[k][q] = inb[k][q] ? ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) : 0;
+            }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                inbm[k][q] = __ballot(inb[k][q]);
+                nzm[k][q] = __ballot(inb[k][q] && ((wv[k][q] >> sh[k][q]) & 1));
+            }
+    }
+
     // pass 1: how far the line reaches in each direction
     int end_t[2];
+#pragma unroll
     for (int k = 0; k < 2; k++) {
         const int sgn = k ? -1 : 1;
         int last_t = 0;
-        for (int base = 0;; base += 64) {
-            int j1, i1;
-            wk.at(base + lane, sgn, j1, i1);
-            const bool inb = (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
-            bool bit = false;
-            if (inb) bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
-            const uint64_t inb_m = __ballot(inb);
-            uint64_t nz_m = __ballot(bit);
+        bool done = false;
+        auto scan = [&](int base, uint64_t inb_m, uint64_t nz_m) {
             const int first_oob = inb_m == ~0ull ? 64 : __builtin_ctzll(~inb_m);
             if (first_oob < 64) nz_m &= (1ull << first_oob) - 1;
-            bool done = false;
             while (nz_m) {
                 int tt = base + __builtin_ctzll(nz_m);
                 if (tt > last_t + c.line_gap + 1) { done = true; break; }
                 last_t = tt;
                 nz_m &= nz_m - 1;
             }
-            if (done || first_oob < 64 || base + 63 - last_t > c.line_gap) break;
+            if (first_oob < 64 || base + 63 - last_t > c.line_gap) done = true;
+        };
+#pragma unroll
+        for (int q = 0; q < NC; q++)
+            if (!done) scan(q * 64, inbm[k][q], nzm[k][q]);
+        for (int base = NC * 64; !done; base += 64) {   // rare: longer than NC chunks
+            int j1, i1;
+            wk.at(base + lane, sgn, j1, i1);
+            const bool inb = (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
+            bool bit = false;
+            if (inb) bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
+            scan(base, __ballot(inb), __ballot(bit));
         }
         end_t[k] = last_t;
     }
@@ -271,18 +304,26 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
     const bool good = abs(ex1 - ex0) >= c.line_length || abs(ey1 - ey0) >= c.line_length;
 
     // pass 2: clear the mask along the line; an accepted line takes its votes back
+#pragma unroll
     for (int k = 0; k < 2; k++) {
         const int sgn = k ? -1 : 1;
-        for (int base = k; base <= end_t[k]; base += 64) {   // t = 0 is handled by direction 0
+        for (int base = 0; base <= end_t[k]; base += 64) {
             const int t = base + lane;
-            bool bit = false;
-            int j1 = 0, i1 = 0;
-            if (t <= end_t[k]) {
-                wk.at(t, sgn, j1, i1);
-                bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
+            int j1, i1;
+            wk.at(t, sgn, j1, i1);
+            uint64_t bm;
+            if (base < NC * 64) {
+                bm = base == 0 ? nzm[k][0] : (base == 64 ? nzm[k][1] : (base == 128 ? nzm[k][2] : nzm[k][3]));
+            } else {
+                bool bit = false;
+                if (t <= end_t[k]) bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
+                bm = __ballot(bit);
             }
+            const int nvalid = end_t[k] - base + 1;                     // steps of this chunk on the line
+            if (nvalid < 64) bm &= (1ull << nvalid) - 1;
+            if (k == 1 && base == 0) bm &= ~1ull;                       // t = 0 belongs to direction 0
+            const bool bit = (bm >> lane) & 1;
             if constexpr (LDS_STATE) {
-                const uint64_t bm = __ballot(bit);
                 if (good && bm) {   // hand the chunk's vote removal to the workgroup, keep walking
                     job_finish(jb, inflight, c, lane);       // one job in flight at a time
                     ++jobseq;
@@ -392,6 +433,9 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
     extern __shared__ int16_t lds16[];
     __shared__ int progress;
     __shared__ Jobs jobs;
+    // this kernel is a few latency-bound wavefronts per CU: let them issue ahead of the streaming
+    // kernels of other batches that share the SIMDs
+    __builtin_amdgcn_s_setprio(3);
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
     const int n = npoints[f];
@@ -600,15 +644,20 @@ void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, const int *row
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
                  int numangle, int numrho, int32_t *acc, hipStream_t st) {
     (void)g;
-    // angle rows per block: as many as fit 64 KiB of LDS (two blocks per CU), at least one
-    int apg = (64 * 1024) / (numrho * 4);
+    // angle rows per block: what fits 6 KiB of LDS, at least one.  Small on purpose: the kernel then shares
+    // CUs with the HoughLinesP kernel of the previous batch, which leaves only a few KiB of LDS free.
+    int apg = (6 * 1024) / (numrho * 4);
     if (apg < 1) apg = 1;
     if (apg > numangle) apg = numangle;
     int groups = (numangle + apg - 1) / apg;
     apg = (numangle + groups - 1) / groups;
     size_t lds = (size_t)apg * numrho * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_vote, dim3(groups, nframes), dim3(1024), lds, st, nz, nz_cap, npoints, tab, numangle, numrho, apg, acc);
+    static size_t attr_set = 0;
+    if (lds > 64 * 1024 && lds > attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL(k_vote, dim3(groups, nframes), dim3(256), lds, st, nz, nz_cap, npoints, tab, numangle, numrho, apg, acc);
 }
 
 void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
@@ -620,9 +669,15 @@ void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoint
     const size_t lds_max = 160 * 1024 - 1024;   // minus the kernel's static LDS (job block, progress word)
     bool fast = false;
     if (numangle <= 64 && acc_bytes + 4096 <= lds_max) {
-        const int lds_points = std::min((int)((lds_max - acc_bytes) / 4), rng_len);
+        // the point list takes at most 32 KiB so that a few KiB of every CU's LDS stay free for the small
+        // kernels of the next batch (hysteresis closure, vote) running beside this one
+        const int lds_points = std::min(std::min((int)((lds_max - acc_bytes) / 4), rng_len), 8192);
         const size_t lds = acc_bytes + 4 * (size_t)lds_points;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static size_t fast_attr = 0;
+        if (lds > fast_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            fast_attr = lds;
+        }
         hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(256), lds, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, fallback, lds_points, rng_out);
         fast = true;
