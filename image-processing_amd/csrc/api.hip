@@ -570,6 +570,7 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
 struct Slot {
     Work w;
     hipStream_t st = nullptr;
+    hipStream_t st_lines = nullptr;   // the pipeline's HoughLinesP stream (not owned; null: the kernel runs on st)
     hipEvent_t ev[10] = {};
     int nframes = 0;
     const uint8_t *input = nullptr;   // device pointer of the frames of the batch in flight
@@ -587,6 +588,9 @@ struct lc_pipe {
     int low = 0, high = 0, line_length = 0, line_gap = 0;
     DevBuf<uint64_t> roi_bits;
     bool has_roi = false;
+    // HoughLinesP kernels of all slots run on this one high-priority stream: they want a whole CU's LDS
+    // each, so two of them never overlap anyway, and every further stream costs a hardware queue.
+    hipStream_t st_lines = nullptr;
     std::vector<Slot> slots;
 };
 
@@ -612,12 +616,19 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
         launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, s.st);
     (void)hipEventRecord(s.ev[EV_VOTE], s.st);
     if (p.want_segments) {
-        (void)hipMemsetAsync(w.status.p, 0, sizeof(int), s.st);
+        // One workgroup per frame that wants a whole CU's LDS: on its own high-priority stream the
+        // dispatcher places it ahead of the next batch's front-end waves instead of behind them.
+        hipStream_t ls = s.st_lines ? s.st_lines : s.st;
+        if (s.st_lines) (void)hipStreamWaitEvent(ls, s.ev[EV_VOTE], 0);
+        (void)hipMemsetAsync(w.status.p, 0, sizeof(int), ls);
         launch_ppht(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
                     p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p, w.fallback.p,
-                    w.rng_out.p, RNG_TABLE, s.st);
+                    w.rng_out.p, RNG_TABLE, ls);
+        (void)hipEventRecord(s.ev[EV_LINES], ls);
+        if (s.st_lines) (void)hipStreamWaitEvent(s.st, s.ev[EV_LINES], 0);
+    } else {
+        (void)hipEventRecord(s.ev[EV_LINES], s.st);
     }
-    (void)hipEventRecord(s.ev[EV_LINES], s.st);
     if (p.want_segments) {
         (void)hipMemcpyAsync(s.h_segcount, w.segcount.p, sizeof(int) * n, hipMemcpyDeviceToHost, s.st);
         (void)hipMemcpyAsync(s.h_seg, w.seg.p, sizeof(int32_t) * 4 * (size_t)n * w.seg_cap, hipMemcpyDeviceToHost, s.st);
@@ -708,10 +719,18 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         pp->has_roi = true;
     }
 
+    const char *pr = getenv("LANECV_LINES_PRIORITY");
+    if (p.want_segments && !(pr && pr[0] == '0')) {
+        int lo_pri = 0, hi_pri = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+        hipError_t e = hipStreamCreateWithPriority(&pp->st_lines, hipStreamNonBlocking, (pr && pr[0] == '2') ? lo_pri : hi_pri);
+        if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "hipStreamCreateWithPriority failed: %s", hipGetErrorString(e)); }
+    }
     pp->slots.resize(p.nslots);
     for (Slot &s : pp->slots) {
         hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
         if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+        s.st_lines = pp->st_lines;
         for (auto &ev : s.ev) {
             e = hipEventCreate(&ev);
             if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
@@ -753,6 +772,7 @@ int lc_pipe_destroy(lc_pipe *pipe) {
         if (s.h_segcount) (void)hipHostFree(s.h_segcount);
         if (s.h_seg) (void)hipHostFree(s.h_seg);
     }
+    if (pipe->st_lines) { (void)hipStreamSynchronize(pipe->st_lines); (void)hipStreamDestroy(pipe->st_lines); }
     delete pipe;
     return LC_OK;
 }
