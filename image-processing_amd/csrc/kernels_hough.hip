@@ -151,6 +151,9 @@ __device__ long long g_stamps[8];   // diagnostic build only: cycle sums of fram
 __device__ unsigned long long g_dbg[4];
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
+#ifndef PPHT_Q
+#define PPHT_Q 4   // points voting speculatively per group in the LDS path
+#endif
 constexpr int LDS_BIAS = 0x4000;   // offset of the 16-bit accumulator bins kept in LDS
 
 // Per-frame constants of one HoughLinesP run.
@@ -506,11 +509,23 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
     }
 
     // consumer.  Points are taken 64 at a time: lane t loads point k + t and its mask word, a ballot
-    // says which are still alive (dead ones cost nothing).  Alive points vote four at a time with
+    // says which are still alive (dead ones cost nothing).  Alive points vote Q at a time with
     // returning LDS atomics issued back to back; if one of them reaches the threshold the votes of the
     // later ones are taken back, the line is extracted and the batch restarts behind that point, so
     // every count any point sees is the one OpenCV's strictly sequential loop would see.
+    // The vote itself is straight-line code: a missing point of a short group and the lanes past the
+    // last angle add zero to a harmless bin instead of branching around the atomic.
     uint32_t *words = reinterpret_cast<uint32_t *>(c.lacc);
+    const uint32_t lane_base = lane < numangle ? (uint32_t)(lane * numrho) : (uint32_t)(lane * 2);
+    const uint32_t lane_one = lane < numangle ? 1u : 0u;
+    const uint64_t lanes_mask = numangle >= 64 ? ~0ull : ((1ull << numangle) - 1);
+    // count after the vote >= threshold  <=>  biased 16-bit bin before the vote >= threshold - 1 + bias
+    const uint32_t thr_b = (uint32_t)min(max((long long)threshold - 1 + LDS_BIAS, 0ll), 0x10000ll);
+    // cvRound of |v| < 2^22: adding 1.5 * 2^23 rounds v half-to-even into the low mantissa bits
+    constexpr float ROUND_MAGIC = 12582912.0f;
+    const uint32_t rfix = (uint32_t)c.half - 0x4B400000u;
+    const uint32_t rho_last = (uint32_t)(numrho - 1);
+    uint32_t r_seen = 0;   // largest (unsigned) bin number any vote produced; out of range means a bad table
     int nseg = 0, jobseq = 0;
 #ifdef LC_STAMPS
     long long t_wait = 0, t_vote = 0, t_line = 0, n_alive = 0, n_line = 0, tc0 = STAMP();
@@ -530,81 +545,74 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
             const uint64_t w = ld_l2(c.mask + (size_t)(ptv >> 16) * c.TX + ((ptv & 0xFFFF) >> 6));
             alive_l = (w >> (ptv & 63)) & 1;
         }
+        const float fjv = (float)(ptv & 0xFFFF), fiv = (float)(ptv >> 16);
         uint64_t alive = __ballot(alive_l);
 #ifdef LC_STAMPS
         t_wait += STAMP() - tw;
 #endif
         bool restarted = false;
         while (alive && !restarted) {
-            constexpr int Q = 4;
-            int tq[Q], pj[Q], pi[Q], key[Q];
-            uint32_t inc[Q], widx[Q];
+            constexpr int Q = PPHT_Q;
+            int tq[Q];
+            uint32_t inc[Q], widx[Q], sh[Q], old[Q];
+            uint64_t vmask[Q];
 #ifdef LC_STAMPS
             long long tv = STAMP();
 #endif
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                tq[q] = -1; key[q] = INT_MIN; inc[q] = 0; widx[q] = 0; pj[q] = pi[q] = 0;
-                if (alive) {
-                    tq[q] = __builtin_ctzll(alive);
-                    alive &= alive - 1;
-                    const uint32_t pt = (uint32_t)__builtin_amdgcn_readlane((int)ptv, tq[q]);
-                    pj[q] = pt & 0xFFFF; pi[q] = pt >> 16;
-                }
-            }
-            uint32_t old[Q];
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                old[q] = 0;
-                if (tq[q] >= 0 && lane < numangle) {
-                    const int r = rho_bin(pj[q], pi[q], my_c, my_s, c.half);
-                    if ((unsigned)r >= (unsigned)numrho) atomicOr(status, 2);
-                    else {
-                        const int a = lane * numrho + r;
-                        widx[q] = a >> 1;
-                        inc[q] = (a & 1) ? 0x10000u : 1u;
-                        old[q] = atomicAdd(&words[widx[q]], inc[q]);
-                    }
-                }
+                const bool valid = alive != 0;
+                tq[q] = valid ? __builtin_ctzll(alive) : 0;
+                alive &= alive - 1;
+                vmask[q] = valid ? lanes_mask : 0ull;
+                const float fj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), tq[q]));
+                const float fi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), tq[q]));
+                const float v = __fadd_rn(__fmul_rn(fj, my_c), __fmul_rn(fi, my_s));
+                uint32_t r = __float_as_uint(__fadd_rn(v, ROUND_MAGIC)) + rfix;   // cvRound(v) + half
+                r_seen = max(r_seen, r);
+                r = min(r, rho_last);
+                const uint32_t a = lane_base + r;
+                sh[q] = (a & 1u) << 4;               // two biased 16-bit bins per word
+                widx[q] = a >> 1;
+                inc[q] = (valid ? lane_one : 0u) << sh[q];
+                old[q] = atomicAdd(&words[widx[q]], inc[q]);
             }
             // a point starts a line iff some angle's count reaches the threshold: one compare and a ballot
             // per point; the arg-max over the angles is only needed for the rare point that does
-            uint64_t trig[Q];
+            uint64_t trig[Q], any = 0;
+            uint32_t val[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                int val = INT_MIN;
-                if (inc[q]) val = (int)((inc[q] == 1u ? old[q] : (old[q] >> 16)) & 0xFFFFu) + 1 - LDS_BIAS;
-                key[q] = val;
-                trig[q] = __ballot(val >= threshold);
+                val[q] = (old[q] >> sh[q]) & 0xFFFFu;
+                trig[q] = __ballot(val[q] >= thr_b) & vmask[q];
+                any |= trig[q];
             }
 #ifdef LC_STAMPS
             t_vote += STAMP() - tv;
 #endif
-            int hit = -1;   // first point of the batch, in OpenCV's order, that starts a line
+            if (any) {
+                int hit = Q - 1;   // first point of the group, in OpenCV's order, that starts a line
 #pragma unroll
-            for (int q = Q - 1; q >= 0; q--)
-                if (tq[q] >= 0 && trig[q] != 0) hit = q;
-#ifdef LC_STAMPS
-#pragma unroll
-            for (int q = 0; q < Q; q++) n_alive += (tq[q] >= 0 && (hit < 0 || q <= hit)) ? 1 : 0;
-#endif
-            if (hit >= 0) {
-                int hkey = key[0], hj = pj[0], hi = pi[0], ht = tq[0];
+                for (int q = Q - 2; q >= 0; q--)
+                    if (trig[q] != 0) hit = q;
+                uint32_t hval = val[0];
+                int ht = tq[0];
 #pragma unroll
                 for (int q = 1; q < Q; q++)
-                    if (hit == q) { hkey = key[q]; hj = pj[q]; hi = pi[q]; ht = tq[q]; }
+                    if (hit == q) { hval = val[q]; ht = tq[q]; }
+                const uint32_t hpt = (uint32_t)__builtin_amdgcn_readlane((int)ptv, ht);
                 // count first, then the smaller angle index (OpenCV keeps the first maximum)
-                const int kmax = wave_max_i32(hkey == INT_MIN ? INT_MIN : hkey * 64 + (63 - lane));
+                const int kmax = wave_max_i32(lane < numangle ? (int)(hval * 64u) + (63 - lane) : -1);
                 const int max_n = 63 - (kmax & 63);
                 // the points behind it have not voted yet in OpenCV's order: take their votes back
 #pragma unroll
                 for (int e = 1; e < Q; e++)
-                    if (e > hit && inc[e]) atomicSub(&words[widx[e]], inc[e]);
+                    if (e > hit) atomicSub(&words[widx[e]], inc[e]);
 #ifdef LC_STAMPS
                 long long tl = STAMP();
                 n_line++;
 #endif
-                const int lr = extract_line<true>(c, lane, hj, hi, max_n, nseg, &jobs, jobseq);
+                const int lr = extract_line<true>(c, lane, (int)(hpt & 0xFFFF), (int)(hpt >> 16), max_n, nseg, &jobs, jobseq);
                 jobseq = lr >> 1;
                 if (lr & 1) nseg++;
 #ifdef LC_STAMPS
@@ -616,8 +624,7 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
         }
         if (!restarted) k += m;
     }
-#ifdef LC_STAMPS
-#endif
+    if (__ballot(r_seen > rho_last) != 0 && lane == 0) atomicOr(status, 2);
     if (lane == 0) *(volatile int *)&jobs.seq = -1;   // helpers leave
     if (lane == 0) seg_count[f] = nseg;
 #ifdef LC_STAMPS
