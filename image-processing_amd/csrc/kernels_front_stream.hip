@@ -2,22 +2,33 @@
 // one pass over the frame with everything between the 12-byte-per-lane HBM load and the bit-plane
 // store held in registers.
 //
-// A wavefront owns a strip of 256 pixel columns (lane l holds 4 consecutive pixels, packed) and
-// streams down a segment of rows.  Horizontal neighbours come from the adjacent lanes through
-// DPP wave shifts, vertical neighbours from short register windows (5 rows of horizontal blur
-// sums, 3 rows of Sobel partial sums, 3 rows of magnitudes).  The outer lanes 0 and 63 are halo
-// (blur 2 + Sobel 1 + NMS 1 = 4 pixels = one lane each side), so a strip emits 248 columns = 31
-// whole bytes of each bit plane per row.
+// A wavefront owns a strip of 256 pixel columns (lane l holds 4 consecutive pixels) and streams down
+// a segment of rows.  Horizontal neighbours come from the adjacent lanes through DPP wave shifts,
+// vertical neighbours from three-row register windows.  The outer lanes 0 and 63 are halo (blur 2 +
+// Sobel 1 + NMS 1 = 4 pixels = one lane each side), so a strip emits 248 columns = 31 whole bytes of
+// each bit plane per row.
+//
+// Everything that depends only on the row is wave-uniform (the unit index goes through
+// v_readfirstlane), so row tests are scalar branches.  The row loop is unrolled three times with the
+// windows indexed by the phase, so no register is ever copied to age a window.  Sixteen-bit values
+// live as pairs: `e` = (pixel 0, pixel 2), `o` = (pixel 1, pixel 3) of the lane, and all the
+// per-pixel work from the vertical blur on is packed two-pixels-per-instruction math.
 //
 // Arithmetic (bit-exact with OpenCV's 8U paths):
-//   gray   (c0*k0 + c1*k1 + c2*k2 + 2^14) >> 15 as two v_dot4_u32_u8 over the low / high coefficient bytes
-//   blur   [1 4 6 4 1] horizontally by v_dot4 (<= 4080), vertically in packed u16 (<= 65280), (v + 128) >> 8
+//   gray   T = sum c_i * 2k_i + 2^15 by two v_dot4_u32_u8 (high / low coefficient bytes); gray = byte 2 of T
+//   blur   [1 4 6 4 1] horizontally by v_dot4 (+8), vertically as [1 2 1] applied twice in packed u16
+//          (the +8 becomes the +128 of the rounding), then >> 8
 //   Sobel  separable, packed i16: d = b(x+1) - b(x-1), s = b(x-1) + 2 b(x) + b(x+1),
 //          dx = d(y-1) + 2 d(y) + d(y+1), dy = s(y+1) - s(y-1); magnitude |dx| + |dy|
+//   NMS    direction by the exact 16-bit form of OpenCV's 15-bit tan(22.5) test:
+//          q = floor(|dx| * 13573 / 2^15) = (|dx| * 53 + (|dx| * 5 >> 8)) >> 7   (13573 = 53 * 256 + 5)
+//          horizontal  <=>  |dy| < q + min(|dx|, 1);   vertical  <=>  |dy| > 2 |dx| + q
+//          comparisons are saturating subtractions, selections are v_bfi with 0 / 0xFFFF half masks
 //   borders: gray reflects (101) for the blur, the Sobel input replicates, magnitudes outside the image are 0
 // Requires W % 4 == 0 (lanes are then wholly inside or wholly outside the image); other widths and
 // gray input take the tiled kernel in kernels_edge.hip.
 #include "common.h"
+#include <type_traits>
 
 namespace lanecv {
 namespace {
@@ -31,16 +42,52 @@ __device__ __forceinline__ uint32_t R32(ss2 v) { return __builtin_bit_cast(uint3
 
 // lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the wave's ends receive 0
 __device__ __forceinline__ uint32_t from_left(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t from_right(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot4(a, b, c, false);
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {   // mask ? a : b, bitwise
+    return (mask & a) | (~mask & b);
+}
+// packed u16 saturating a - b (0 where a <= b)
+__device__ __forceinline__ uint32_t satsub(uint32_t a, uint32_t b) {
+    return R32(__builtin_elementwise_sub_sat(U2(a), U2(b)));
+}
+__device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) {
+    return R32(__builtin_elementwise_min(U2(a), U2(b)));
+}
+// The next three are inline assembly so that the optimiser keeps them packed (it otherwise splits the
+// halves again into 16-bit compares and selects).  None of their results feeds a DPP move directly.
+// 0xFFFF in every half whose signed 16-bit value is negative
+__device__ __forceinline__ uint32_t pksign(uint32_t a) {
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+// 1 in every half that is non-zero
+__device__ __forceinline__ uint32_t pknz(uint32_t a) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+// packed 16-bit a * 2 + c (wraps; the same bits for signed and unsigned halves)
+__device__ __forceinline__ uint32_t pkmad2(uint32_t a, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkadd(uint32_t a, uint32_t b) { return R32(U2(a) + U2(b)); }
+__device__ __forceinline__ uint32_t pksub(uint32_t a, uint32_t b) { return R32(U2(a) - U2(b)); }
+__device__ __forceinline__ uint32_t pkabs(uint32_t a) {
+    const ss2 v = S2(a);
+    return R32(__builtin_elementwise_max(v, -v));
 }
 __device__ __forceinline__ int reflect101s(int p, int len) {
     if ((unsigned)p < (unsigned)len) return p;
@@ -54,7 +101,7 @@ __device__ __forceinline__ int reflect101s(int p, int len) {
 struct FrontArgs {
     const uint8_t *src;
     Geo g;
-    uint32_t k_lo, k_hi;     // low / high bytes of the three 15-bit gray weights, in memory channel order
+    uint32_t k_lo, k_hi;     // low / high bytes of twice the three 15-bit gray weights, in memory channel order
     int low, high;
     uint64_t *planeS, *planeW;
     uint8_t *gray_out, *blur_out;
@@ -65,10 +112,12 @@ struct Pair { uint32_t e, o; };   // 4 packed 16-bit values of a lane: e = (px0,
 
 constexpr int STRIP = 248;        // output columns of a wavefront
 
+template <int P> using Phase = std::integral_constant<int, P>;
+
 template <bool BLUR>
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const int lane = threadIdx.x & 63;
-    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int u = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform
     if (u >= a.nunits) return;
     const int s = u % a.nstrips;
     const int sg = (u / a.nstrips) % a.nseg;
@@ -82,45 +131,52 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const int jW = (W - X0) >> 2;                  // the lane that starts at column W
     const bool rb = lane == jW;
     const bool has_border = X0 < 0 || jW <= 63;    // wave-uniform
-    const bool emits = lane >= 1 && lane <= 62;
     const uint8_t *fsrc = a.src + (size_t)f * 3 * W * H;
+    // lanes outside the image load a valid pixel group instead of nothing: what they hold never reaches
+    // an output (border lanes are rewritten below, magnitudes outside the image are forced to zero)
+    const uint32_t lane_off = 3u * (uint32_t)min(max(px, 0), W - 4);
     constexpr int DB = BLUR ? 2 : 0;               // rows the blur delays the pipeline by
     constexpr uint32_t M8 = 0x00FF00FFu;
+    const uint32_t low2 = (uint32_t)min(max(a.low, 0), 32767) * 0x10001u;
+    const uint32_t high2 = (uint32_t)min(max(a.high, 0), 32767) * 0x10001u;
+    // this lane's byte of the two bit planes (odd lanes 1..61 store: their nibble and the next lane's)
+    const int bi = STRIP / 8 * s + ((lane - 1) >> 1);
+    const bool stores = (lane & 1) && lane <= 61 && bi < 8 * TX;
+    const bool emits = lane >= 1 && lane <= 62;
 
-    Pair Hw[5] = {};                               // horizontal blur sums of rows v-4 .. v
-    Pair Dw[3] = {}, Sw[3] = {};                   // Sobel partial sums of Sobel-input rows b-2 .. b
-    Pair Mw[3] = {};                               // magnitudes of rows m-2 .. m
-    Pair DXc = {}, DYc = {}, DXn = {}, DYn = {};   // gradients of row n (centre of the NMS) and row m
+    // three-row windows, slot = phase of the iteration that wrote it
+    Pair Hh[3] = {}, Tt[3] = {};                   // horizontal blur sums (+8), first vertical [1 2 1] pass
+    Pair Dw[3] = {}, Sw[3] = {};                   // Sobel partial sums of the Sobel input rows
+    Pair Mw[3] = {}, Nw[3] = {};                   // magnitudes; Nw.e = left neighbours of the e pixels, Nw.o = right neighbours of the o pixels
+    Pair DXw[3] = {}, DYw[3] = {};                 // gradients
 
-    auto load_row = [&](int v, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
-        int rs = BLUR ? reflect101s(v, H) : (v < 0 ? 0 : (v >= H ? H - 1 : v));
-        r0 = r1 = r2 = 0;
-        if (inimg) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(fsrc + ((size_t)rs * W + px) * 3);
-            r0 = p[0]; r1 = p[1]; r2 = p[2];
-        }
+    uint32_t n0 = 0, n1 = 0, n2 = 0;               // the row loaded one iteration ahead
+    auto load_row = [&](int v) {
+        const int rs = BLUR ? reflect101s(v, H) : (v < 0 ? 0 : (v >= H ? H - 1 : v));
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(fsrc + (size_t)rs * W * 3 + lane_off);
+        n0 = p[0]; n1 = p[1]; n2 = p[2];
     };
 
-    int v = y0 - (DB + 2);
     const int vend = y1 - 1 + DB + 2;
-    uint32_t n0, n1, n2;
-    load_row(v, n0, n1, n2);
-    for (; v <= vend; v++) {
+
+    auto step = [&](auto phase, const int v) {
+        constexpr int P = decltype(phase)::value, PREV = (P + 2) % 3, OLD = (P + 1) % 3;
         const uint32_t w0 = n0, w1 = n1, w2 = n2;
-        if (v < vend) load_row(v + 1, n0, n1, n2);
+        if (v < vend) load_row(v + 1);
 
         // ---- gray: 4 pixels -> one packed dword ------------------------------------------------
         const uint32_t p0 = w0, p1 = alignbyte(w1, w0, 3), p2 = alignbyte(w2, w1, 2), p3 = w2 >> 8;
-        const uint32_t g0 = ((dot4(p0, a.k_hi, 0) << 8) + dot4(p0, a.k_lo, 1u << 14)) >> 15;
-        const uint32_t g1 = ((dot4(p1, a.k_hi, 0) << 8) + dot4(p1, a.k_lo, 1u << 14)) >> 15;
-        const uint32_t g2 = ((dot4(p2, a.k_hi, 0) << 8) + dot4(p2, a.k_lo, 1u << 14)) >> 15;
-        const uint32_t g3 = ((dot4(p3, a.k_hi, 0) << 8) + dot4(p3, a.k_lo, 1u << 14)) >> 15;
-        uint32_t G = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-        if (a.gray_out && v >= y0 && v < y1 && inimg && emits)
-            *reinterpret_cast<uint32_t *>(a.gray_out + (size_t)f * W * H + (size_t)v * W + px) = G;
+        const uint32_t t0 = (dot4(p0, a.k_hi, 0) << 8) + dot4(p0, a.k_lo, 1u << 15);
+        const uint32_t t1 = (dot4(p1, a.k_hi, 0) << 8) + dot4(p1, a.k_lo, 1u << 15);
+        const uint32_t t2 = (dot4(p2, a.k_hi, 0) << 8) + dot4(p2, a.k_lo, 1u << 15);
+        const uint32_t t3 = (dot4(p3, a.k_hi, 0) << 8) + dot4(p3, a.k_lo, 1u << 15);
+        uint32_t G = __builtin_amdgcn_perm(t1, t0, 0x0c0c0602u) | __builtin_amdgcn_perm(t3, t2, 0x06020c0cu);
+        if (a.gray_out && v >= y0 && v < y1) {
+            if (inimg && emits) *reinterpret_cast<uint32_t *>(a.gray_out + (size_t)f * W * H + (size_t)v * W + px) = G;
+        }
 
-        // ---- Sobel input row B (blurred row v-2, or the gray row itself) ------------------------
-        uint32_t B;
+        // ---- Sobel input row (blurred row v-2, or the gray row itself) as pairs -----------------
+        uint32_t be, bo;
         if constexpr (BLUR) {
             if (has_border) {   // reflect 101: columns -1,-2 mirror 1,2; columns W,W+1 mirror W-2,W-3
                 const uint32_t GR0 = from_right(G), GL0 = from_left(G);
@@ -129,114 +185,111 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             }
             const uint32_t GL = from_left(G), GR = from_right(G);
             const uint32_t q0 = alignbyte(G, GL, 2), q1 = alignbyte(G, GL, 3), q3 = alignbyte(GR, G, 1);
-            const uint32_t h0 = dot4(q0, 0x04060401u, dot4(G, 0x00010000u, 0));
-            const uint32_t h1 = dot4(q1, 0x04060401u, dot4(G, 0x01000000u, 0));
-            const uint32_t h2 = dot4(G, 0x04060401u, dot4(GR, 0x00000001u, 0));
-            const uint32_t h3 = dot4(q3, 0x04060401u, dot4(GR, 0x00000100u, 0));
-            Hw[0] = Hw[1]; Hw[1] = Hw[2]; Hw[2] = Hw[3]; Hw[3] = Hw[4];
-            Hw[4].e = h0 | (h2 << 16);
-            Hw[4].o = h1 | (h3 << 16);
-            const us2 ve = U2(Hw[0].e) + U2(Hw[4].e) + (U2(Hw[1].e) + U2(Hw[3].e)) * (unsigned short)4 +
-                           U2(Hw[2].e) * (unsigned short)6;
-            const us2 vo = U2(Hw[0].o) + U2(Hw[4].o) + (U2(Hw[1].o) + U2(Hw[3].o)) * (unsigned short)4 +
-                           U2(Hw[2].o) * (unsigned short)6;
-            const uint32_t be = R32((ve + (unsigned short)128) >> (unsigned short)8);
-            const uint32_t bo = R32((vo + (unsigned short)128) >> (unsigned short)8);
-            B = be | (bo << 8);
+            const uint32_t h0 = dot4(q0, 0x04060401u, dot4(G, 0x00010000u, 8));
+            const uint32_t h1 = dot4(q1, 0x04060401u, dot4(G, 0x01000000u, 8));
+            const uint32_t h2 = dot4(G, 0x04060401u, dot4(GR, 0x00000001u, 8));
+            const uint32_t h3 = dot4(q3, 0x04060401u, dot4(GR, 0x00000100u, 8));
+            Hh[P].e = h0 | (h2 << 16);
+            Hh[P].o = h1 | (h3 << 16);
+            // t(v-1) = h(v-2) + 2 h(v-1) + h(v);  16 (b(v-2) + 8) = t(v-3) + 2 t(v-2) + t(v-1)
+            Tt[P].e = pkmad2(Hh[PREV].e, pkadd(Hh[OLD].e, Hh[P].e));
+            Tt[P].o = pkmad2(Hh[PREV].o, pkadd(Hh[OLD].o, Hh[P].o));
+            be = R32(U2(pkmad2(Tt[PREV].e, pkadd(Tt[OLD].e, Tt[P].e))) >> (unsigned short)8);
+            bo = R32(U2(pkmad2(Tt[PREV].o, pkadd(Tt[OLD].o, Tt[P].o))) >> (unsigned short)8);
             const int bv = v - 2;
-            if (a.blur_out && bv >= y0 && bv < y1 && inimg && emits)
-                *reinterpret_cast<uint32_t *>(a.blur_out + (size_t)f * W * H + (size_t)bv * W + px) = B;
+            if (a.blur_out && bv >= y0 && bv < y1) {
+                if (inimg && emits) *reinterpret_cast<uint32_t *>(a.blur_out + (size_t)f * W * H + (size_t)bv * W + px) = be | (bo << 8);
+            }
         } else {
-            B = G;
+            be = G & M8;
+            bo = (G >> 8) & M8;
         }
         if (has_border) {       // replicate: column -1 copies column 0, column W copies column W-1
-            const uint32_t BR0 = from_right(B), BL0 = from_left(B);
-            if (lb) B = (B & 0x00FFFFFFu) | (BR0 << 24);
-            if (rb) B = (B & 0xFFFFFF00u) | (BL0 >> 24);
+            const uint32_t r = from_right(be), l = from_left(bo);
+            if (lb) bo = (bo & 0x0000FFFFu) | (r << 16);
+            if (rb) be = (be & 0xFFFF0000u) | (l >> 16);
         }
 
         // ---- Sobel, horizontal part of row b = v - DB -------------------------------------------
         {
-            const uint32_t BL = from_left(B), BR = from_right(B);
-            const uint32_t bm = alignbyte(B, BL, 3), bp = alignbyte(BR, B, 1);
-            const uint32_t ce = B & M8, co = (B >> 8) & M8;
-            const uint32_t me = bm & M8, mo = (bm >> 8) & M8;
-            const uint32_t pe = bp & M8, po = (bp >> 8) & M8;
-            Dw[0] = Dw[1]; Dw[1] = Dw[2];
-            Sw[0] = Sw[1]; Sw[1] = Sw[2];
-            Dw[2].e = R32(S2(pe) - S2(me));
-            Dw[2].o = R32(S2(po) - S2(mo));
-            Sw[2].e = R32(U2(me) + U2(pe) + U2(ce) * (unsigned short)2);
-            Sw[2].o = R32(U2(mo) + U2(po) + U2(co) * (unsigned short)2);
+            const uint32_t le = alignbyte(bo, from_left(bo), 2);    // (px-1, px1): left neighbours of the e pixels
+            const uint32_t ro = alignbyte(from_right(be), be, 2);   // (px2, px4): right neighbours of the o pixels
+            Dw[P].e = pksub(bo, le);
+            Dw[P].o = pksub(ro, be);
+            Sw[P].e = pkmad2(be, pkadd(le, bo));
+            Sw[P].o = pkmad2(bo, pkadd(be, ro));
         }
 
         // ---- Sobel, vertical part, and magnitude of row m = b - 1 --------------------------------
         const int m_row = v - DB - 1;
         {
-            const int ip = m_row == 0 ? 1 : 0, in = m_row == H - 1 ? 1 : 2;   // replicate above / below
-            const Pair dP = ip ? Dw[1] : Dw[0], dN = in == 1 ? Dw[1] : Dw[2];
-            const Pair sP = ip ? Sw[1] : Sw[0], sN = in == 1 ? Sw[1] : Sw[2];
-            DXc = DXn; DYc = DYn;
-            const ss2 dxe = S2(dP.e) + S2(Dw[1].e) * (short)2 + S2(dN.e);
-            const ss2 dxo = S2(dP.o) + S2(Dw[1].o) * (short)2 + S2(dN.o);
-            const ss2 dye = S2(sN.e) - S2(sP.e);
-            const ss2 dyo = S2(sN.o) - S2(sP.o);
-            DXn.e = R32(dxe); DXn.o = R32(dxo); DYn.e = R32(dye); DYn.o = R32(dyo);
+            if (m_row == 0) { Dw[OLD] = Dw[PREV]; Sw[OLD] = Sw[PREV]; }        // replicate above
+            if (m_row == H - 1) { Dw[P] = Dw[PREV]; Sw[P] = Sw[PREV]; }        // replicate below
+            DXw[P].e = pkmad2(Dw[PREV].e, pkadd(Dw[OLD].e, Dw[P].e));
+            DXw[P].o = pkmad2(Dw[PREV].o, pkadd(Dw[OLD].o, Dw[P].o));
+            DYw[P].e = pksub(Sw[P].e, Sw[OLD].e);
+            DYw[P].o = pksub(Sw[P].o, Sw[OLD].o);
             const bool live = inimg && m_row >= 0 && m_row < H;
-            const ss2 mge = __builtin_elementwise_max(dxe, -dxe) + __builtin_elementwise_max(dye, -dye);
-            const ss2 mgo = __builtin_elementwise_max(dxo, -dxo) + __builtin_elementwise_max(dyo, -dyo);
-            Mw[0] = Mw[1]; Mw[1] = Mw[2];
-            Mw[2].e = live ? R32(mge) : 0u;
-            Mw[2].o = live ? R32(mgo) : 0u;
+            const uint32_t mge = pkadd(pkabs(DXw[P].e), pkabs(DYw[P].e));
+            const uint32_t mgo = pkadd(pkabs(DXw[P].o), pkabs(DYw[P].o));
+            Mw[P].e = live ? mge : 0u;
+            Mw[P].o = live ? mgo : 0u;
+            Nw[P].e = alignbyte(Mw[P].o, from_left(Mw[P].o), 2);
+            Nw[P].o = alignbyte(from_right(Mw[P].e), Mw[P].e, 2);
         }
 
         // ---- non-maximum suppression + thresholds of row n = m - 1 -----------------------------
         const int n_row = m_row - 1;
         if (n_row >= y0 && n_row < y1) {
-            const uint32_t ce = Mw[1].e, co = Mw[1].o;
+            const uint32_t ce = Mw[PREV].e, co = Mw[PREV].o;
             const us2 mx = __builtin_elementwise_max(U2(ce), U2(co));
             const int mmax = max((int)(R32(mx) & 0xFFFFu), (int)(R32(mx) >> 16));
             uint32_t nib = 0;    // bits 0-3 strong, bits 8-11 weak
             if (__ballot(mmax > a.low) != 0) {
-                int up[6], cu[6], dn[6];
-                {
-                    const uint32_t l0 = from_left(Mw[0].o), r0 = from_right(Mw[0].e);
-                    const uint32_t l1 = from_left(co), r1 = from_right(ce);
-                    const uint32_t l2 = from_left(Mw[2].o), r2 = from_right(Mw[2].e);
-                    up[0] = l0 >> 16; up[1] = Mw[0].e & 0xFFFF; up[2] = Mw[0].o & 0xFFFF; up[3] = Mw[0].e >> 16; up[4] = Mw[0].o >> 16; up[5] = r0 & 0xFFFF;
-                    cu[0] = l1 >> 16; cu[1] = ce & 0xFFFF; cu[2] = co & 0xFFFF; cu[3] = ce >> 16; cu[4] = co >> 16; cu[5] = r1 & 0xFFFF;
-                    dn[0] = l2 >> 16; dn[1] = Mw[2].e & 0xFFFF; dn[2] = Mw[2].o & 0xFFFF; dn[3] = Mw[2].e >> 16; dn[4] = Mw[2].o >> 16; dn[5] = r2 & 0xFFFF;
-                }
-                int dxs[4], dys[4];
-                dxs[0] = (short)(DXc.e & 0xFFFF); dxs[1] = (short)(DXc.o & 0xFFFF); dxs[2] = (int)DXc.e >> 16; dxs[3] = (int)DXc.o >> 16;
-                dys[0] = (short)(DYc.e & 0xFFFF); dys[1] = (short)(DYc.o & 0xFFFF); dys[2] = (int)DYc.e >> 16; dys[3] = (int)DYc.o >> 16;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int m = cu[k + 1];
-                    const int ax = abs(dxs[k]), ay = abs(dys[k]) << 15;
-                    const int tg22x = ax * 13573;
-                    const bool horiz = ay < tg22x;
-                    const bool vert = !horiz && ay > tg22x + (ax << 16);
-                    const bool opp = (dxs[k] ^ dys[k]) < 0;      // gradient along the anti-diagonal
-                    const int a1 = horiz ? cu[k] : (vert ? up[k + 1] : (opp ? up[k + 2] : up[k]));
-                    const int a2 = horiz ? cu[k + 2] : (vert ? dn[k + 1] : (opp ? dn[k] : dn[k + 2]));
-                    const bool second_ge = horiz || vert;        // OpenCV: '>' then '>=' on the axes, '>' twice on diagonals
-                    const bool keep = m > a.low && m > a1 && (second_ge ? m >= a2 : m > a2);
-                    const bool strong = keep && m > a.high;
-                    nib |= (strong ? 1u : 0u) << k;
-                    nib |= ((keep && !strong) ? 1u : 0u) << (8 + k);
-                }
+                // one pair of pixels: m against its two neighbours along the gradient
+                auto nms = [&](uint32_t m, uint32_t dx, uint32_t dy, uint32_t cl, uint32_t cr, uint32_t ul, uint32_t uc,
+                               uint32_t ur, uint32_t dl, uint32_t dc, uint32_t dr, uint32_t &sbit, uint32_t &wbit) {
+                    const uint32_t ax = pkabs(dx), ay = pkabs(dy);
+                    const uint32_t q = R32((U2(ax) * (unsigned short)53 + ((U2(ax) * (unsigned short)5) >> (unsigned short)8)) >> (unsigned short)7);
+                    const uint32_t hz = pkadd(q, pknz(ax));
+                    const uint32_t vt = pkmad2(ax, q);
+                    const uint32_t Hm = pksign(pksub(ay, hz));      // 0xFFFF where |dy| < hz
+                    const uint32_t Vm = pksign(pksub(vt, ay));      // 0xFFFF where |dy| > vt
+                    const uint32_t Om = pksign(dx ^ dy);            // 0xFFFF where dx, dy differ in sign
+                    const uint32_t a1 = bfi(Hm, cl, bfi(Vm, uc, bfi(Om, ur, ul)));
+                    const uint32_t a2 = bfi(Hm, cr, bfi(Vm, dc, bfi(Om, dl, dr)));
+                    const uint32_t m2 = pksub(m, Hm | Vm);          // m + 1 on the axes: '>=' there
+                    const uint32_t keep = pkmin(satsub(m, low2), pkmin(satsub(m, a1), satsub(m2, a2)));
+                    const uint32_t strong = pkmin(keep, satsub(m, high2));
+                    sbit = pknz(strong);
+                    wbit = pknz(keep) ^ sbit;
+                };
+                uint32_t se, we, so, wo;
+                nms(ce, DXw[PREV].e, DYw[PREV].e, Nw[PREV].e, co, Nw[OLD].e, Mw[OLD].e, Mw[OLD].o, Nw[P].e, Mw[P].e, Mw[P].o, se, we);
+                nms(co, DXw[PREV].o, DYw[PREV].o, ce, Nw[PREV].o, Mw[OLD].e, Mw[OLD].o, Nw[OLD].o, Mw[P].e, Mw[P].o, Nw[P].o, so, wo);
+                const uint32_t xs = se | (so << 1), xw = we | (wo << 1);   // bits 0,1 = px0,px1; bits 16,17 = px2,px3
+                nib = ((xs | (xs >> 14)) & 0xFu) | (((xw | (xw >> 14)) & 0xFu) << 8);
             }
             // two lanes make a byte of each plane: odd lane 2i+1 takes lane 2i+2's nibble
-            const uint32_t nb = from_right(nib);
-            const uint32_t both = nib | (nb << 4);
-            const int bi = STRIP / 8 * s + ((lane - 1) >> 1);
-            if ((lane & 1) && lane <= 61 && bi < 8 * TX) {
-                const size_t rowb = ((size_t)f * H + n_row) * TX * 8 + bi;
-                reinterpret_cast<uint8_t *>(a.planeS)[rowb] = (uint8_t)(both & 0xFF);
-                reinterpret_cast<uint8_t *>(a.planeW)[rowb] = (uint8_t)((both >> 8) & 0xFF);
+            const uint32_t both = nib | (from_right(nib) << 4);
+            uint8_t *rowS = reinterpret_cast<uint8_t *>(a.planeS) + ((size_t)f * H + n_row) * TX * 8;
+            uint8_t *rowW = reinterpret_cast<uint8_t *>(a.planeW) + ((size_t)f * H + n_row) * TX * 8;
+            if (stores) {
+                rowS[bi] = (uint8_t)(both & 0xFF);
+                rowW[bi] = (uint8_t)((both >> 8) & 0xFF);
             }
         }
+    };
+
+    int v = y0 - (DB + 2);
+    load_row(v);
+    for (;;) {
+        if (v > vend) break;
+        step(Phase<0>{}, v); v++;
+        if (v > vend) break;
+        step(Phase<1>{}, v); v++;
+        if (v > vend) break;
+        step(Phase<2>{}, v); v++;
     }
 }
 
@@ -250,7 +303,8 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     FrontArgs a;
     a.src = src; a.g = g; a.low = low; a.high = high;
     a.planeS = planeS; a.planeW = planeW; a.gray_out = gray_out; a.blur_out = blur_out;
-    const uint32_t k0 = code == 6 ? 3735 : 9798, k1 = 19235, k2 = code == 6 ? 9798 : 3735;
+    // twice the 15-bit weights, so that the gray value lands on a byte boundary of the sum
+    const uint32_t k0 = 2 * (code == 6 ? 3735 : 9798), k1 = 2 * 19235, k2 = 2 * (code == 6 ? 9798 : 3735);
     a.k_lo = (k0 & 255) | ((k1 & 255) << 8) | ((k2 & 255) << 16);
     a.k_hi = (k0 >> 8) | ((k1 >> 8) << 8) | ((k2 >> 8) << 16);
     a.nstrips = (TILE * g.TX + STRIP - 1) / STRIP;   // every byte of every plane row is written
