@@ -150,19 +150,33 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     Pair Mw[3] = {}, Nw[3] = {};                   // magnitudes; Nw.e = left neighbours of the e pixels, Nw.o = right neighbours of the o pixels
     Pair DXw[3] = {}, DYw[3] = {};                 // gradients
 
-    uint32_t n0 = 0, n1 = 0, n2 = 0;               // the row loaded one iteration ahead
-    auto load_row = [&](int v) {
+    // Memory traffic is issued once per group of three rows, at the top of the group: the loads of the
+    // NEXT group's rows and the plane bytes of the PREVIOUS group.  The only wait for memory (the
+    // hardware counts loads and stores in one counter) then covers operations issued a whole group
+    // earlier, so neither the HBM latency nor the store acknowledgements stall the arithmetic.
+    uint32_t Lc[3][3] = {}, Ln[3][3] = {};         // rows of the current / next group
+    uint32_t pend[3] = {};                         // plane bytes of the group just finished (strong | weak << 8)
+    auto load_row = [&](int v, uint32_t (&r)[3]) {
         const int rs = BLUR ? reflect101s(v, H) : (v < 0 ? 0 : (v >= H ? H - 1 : v));
         const uint32_t *p = reinterpret_cast<const uint32_t *>(fsrc + (size_t)rs * W * 3 + lane_off);
-        n0 = p[0]; n1 = p[1]; n2 = p[2];
+        r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
+    };
+    auto store_row = [&](int n_row, uint32_t both) {
+        if (n_row >= y0 && n_row < y1) {
+            uint8_t *rowS = reinterpret_cast<uint8_t *>(a.planeS) + ((size_t)f * H + n_row) * TX * 8;
+            uint8_t *rowW = reinterpret_cast<uint8_t *>(a.planeW) + ((size_t)f * H + n_row) * TX * 8;
+            if (stores) {
+                rowS[bi] = (uint8_t)(both & 0xFF);
+                rowW[bi] = (uint8_t)((both >> 8) & 0xFF);
+            }
+        }
     };
 
     const int vend = y1 - 1 + DB + 2;
 
     auto step = [&](auto phase, const int v) {
         constexpr int P = decltype(phase)::value, PREV = (P + 2) % 3, OLD = (P + 1) % 3;
-        const uint32_t w0 = n0, w1 = n1, w2 = n2;
-        if (v < vend) load_row(v + 1);
+        const uint32_t w0 = Lc[P][0], w1 = Lc[P][1], w2 = Lc[P][2];
 
         // ---- gray: 4 pixels -> one packed dword ------------------------------------------------
         const uint32_t p0 = w0, p1 = alignbyte(w1, w0, 3), p2 = alignbyte(w2, w1, 2), p3 = w2 >> 8;
@@ -271,26 +285,24 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
                 nib = ((xs | (xs >> 14)) & 0xFu) | (((xw | (xw >> 14)) & 0xFu) << 8);
             }
             // two lanes make a byte of each plane: odd lane 2i+1 takes lane 2i+2's nibble
-            const uint32_t both = nib | (from_right(nib) << 4);
-            uint8_t *rowS = reinterpret_cast<uint8_t *>(a.planeS) + ((size_t)f * H + n_row) * TX * 8;
-            uint8_t *rowW = reinterpret_cast<uint8_t *>(a.planeW) + ((size_t)f * H + n_row) * TX * 8;
-            if (stores) {
-                rowS[bi] = (uint8_t)(both & 0xFF);
-                rowW[bi] = (uint8_t)((both >> 8) & 0xFF);
-            }
+            pend[P] = nib | (from_right(nib) << 4);
         }
     };
 
     int v = y0 - (DB + 2);
-    load_row(v);
-    for (;;) {
-        if (v > vend) break;
-        step(Phase<0>{}, v); v++;
-        if (v > vend) break;
-        step(Phase<1>{}, v); v++;
-        if (v > vend) break;
-        step(Phase<2>{}, v); v++;
+    load_row(v, Ln[0]); load_row(v + 1, Ln[1]); load_row(v + 2, Ln[2]);
+    for (; v <= vend; v += 3) {
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) Lc[p][q] = Ln[p][q];
+        if (v + 3 <= vend) { load_row(v + 3, Ln[0]); load_row(v + 4, Ln[1]); load_row(v + 5, Ln[2]); }
+        store_row(v - 3 - DB - 2, pend[0]); store_row(v - 2 - DB - 2, pend[1]); store_row(v - 1 - DB - 2, pend[2]);
+        step(Phase<0>{}, v);
+        step(Phase<1>{}, v + 1);
+        step(Phase<2>{}, v + 2);
     }
+    store_row(v - 3 - DB - 2, pend[0]); store_row(v - 2 - DB - 2, pend[1]); store_row(v - 1 - DB - 2, pend[2]);
 }
 
 }  // namespace
