@@ -164,58 +164,104 @@ struct Ppht {
     int16_t *lacc;             // LDS accumulator (fast path)
     int32_t *acc;              // global accumulator (general path)
     int32_t *seg;
+    // fast path: the frame's edge bits live in LDS, only the word span of every row that has points
+    uint64_t *lmask;           // the spans, back to back
+    const uint32_t *rowtab;    // per row ymin + r: first LDS word (bits 0-15), first image word (16-23), words (24-31)
+    int ymin, nrows;
 };
+
+// Edge bit of pixel (j, i) in the LDS copy; widx is the LDS word that holds it (valid when the result is true).
+__device__ __forceinline__ bool lds_mask_bit(const Ppht &c, int j, int i, uint32_t &widx) {
+    const unsigned r = (unsigned)(i - c.ymin);
+    if (r >= (unsigned)c.nrows) return false;
+    const uint32_t e = c.rowtab[r];
+    const unsigned wi = (unsigned)(j >> 6) - ((e >> 16) & 0xFFu);
+    if (wi >= (e >> 24)) return false;
+    widx = (e & 0xFFFFu) + wi;
+    return (c.lmask[widx] >> (j & 63)) & 1;
+}
 
 // ---- vote removal spread over the wavefronts of the workgroup (fast path) --------------------
-// The line-walking wavefront (wave 0) posts one job per 64-step chunk of an accepted line: the
-// chunk's walk parameters and the ballot of its edge pixels.  Three wavefronts share a job
-// statically -- wave 0 and the two helper waves take angle groups p, p + 3, p + 6, ... -- and
-// subtract the chunk's votes for their angles (lane = pixel).  One job is in flight at a time and
-// every participant reports before the next is posted, so helpers see every job exactly once.
-constexpr int JOB_ANGLES = 5, JOB_WAVES = 3;
+// The line-walking wavefront (wave 0) posts one job per stretch of LINE_NC * 64 steps of an accepted
+// line (most lines are one job): the walk parameters and, per direction and 64-step chunk, the ballot
+// of the edge pixels whose votes go.  JOB_WORKERS wavefronts -- wave 0 itself and the helper waves --
+// share a job by pixel: worker p takes the bits p, p + JOB_WORKERS, ... of every chunk, derives each
+// pixel from the walk with scalar arithmetic and subtracts its vote with one angle per lane, exactly
+// the shape of the voting step.  One job is in flight at a time and every worker reports before the
+// next is posted, so helpers see every job exactly once.
+constexpr int LINE_NC = 4;                       // 64-step chunks per direction fetched (and posted) together
+constexpr int PPHT_THREADS = 512, JOB_WORKERS = 7;   // waves: 0 consumer, 1 producer, 2..7 helpers
 struct Jobs {
     int seq;                     // jobs posted so far; -1 tells the helpers to leave
-    int done;                    // participants that finished job `seq`
-    int par[16];                 // xflag, x0, y0, dx, dy, sgn, base, bits lo, bits hi
-    float tc[64], ts[64];        // trig table of the (at most 64) angles
+    int done;                    // workers that finished job `seq`
+    int par[6];                  // xflag, x0, y0, dx, dy, first step of the stretch
+    uint32_t bits[2][LINE_NC][2];
 };
 
-__device__ __forceinline__ void job_work(Jobs *jb, int part, const Ppht &c, int lane) {
+// What a lane needs to vote for its angle in the LDS accumulator (two biased 16-bit bins per word).
+struct VoteLane {
+    float c, s;                  // trig pair of this lane's angle (0 past the last angle)
+    uint32_t base;               // first bin of this lane's angle row in the compact accumulator
+    uint32_t one;                // 1 for a real angle, 0 past the last angle
+    uint32_t rfix;               // turns the rounded float's bits into (bin - first reachable bin of this angle)
+    uint32_t wid;                // reachable bins of this angle - 1
+    uint32_t *words;
+};
+// cvRound of |v| < 2^22: adding 1.5 * 2^23 rounds v half-to-even into the low mantissa bits
+constexpr float ROUND_MAGIC = 12582912.0f;
+
+// bin (as a word index and a shift) this lane's angle gives the pixel (fj, fi); over is non-zero if the
+// bin fell outside the angle's reachable range (cannot happen for pixels inside the points' bounding box)
+__device__ __forceinline__ void vote_bin(const VoteLane &vl, float fj, float fi, uint32_t &widx, uint32_t &sh, uint32_t &over) {
+    const float v = __fadd_rn(__fmul_rn(fj, vl.c), __fmul_rn(fi, vl.s));
+    uint32_t r = __float_as_uint(__fadd_rn(v, ROUND_MAGIC)) + vl.rfix;   // cvRound(v) + (numrho - 1) / 2 - first bin
+    const uint32_t rc = min(r, vl.wid);
+    over = r - rc;
+    r = rc;
+    const uint32_t a = vl.base + r;
+    sh = (a & 1u) << 4;
+    widx = a >> 1;
+}
+
+__device__ __forceinline__ void job_work(Jobs *jb, int part, const VoteLane &vl, int lane) {
     Walk wk;
-    wk.xflag = jb->par[0]; wk.x0 = jb->par[1]; wk.y0 = jb->par[2]; wk.dx = jb->par[3]; wk.dy = jb->par[4];
-    const int sgn = jb->par[5], base = jb->par[6];
-    const uint64_t bits = (uint32_t)jb->par[7] | ((uint64_t)(uint32_t)jb->par[8] << 32);
-    const bool bit = (bits >> lane) & 1;
-    int j1, i1;
-    wk.at(base + lane, sgn, j1, i1);
-    uint32_t *words = reinterpret_cast<uint32_t *>(c.lacc);
-    if (bit) {
-        for (int n0 = part * JOB_ANGLES; n0 < c.numangle; n0 += JOB_WAVES * JOB_ANGLES) {
-            const int n1 = min(c.numangle, n0 + JOB_ANGLES);
-            for (int nn = n0; nn < n1; nn++) {
-                const int r = rho_bin(j1, i1, jb->tc[nn], jb->ts[nn], c.half);
-                if ((unsigned)r < (unsigned)c.numrho) {
-                    const int a = nn * c.numrho + r;
-                    // two biased 16-bit bins per word; the bias keeps a half from borrowing out of the other
-                    atomicSub(&words[a >> 1], (a & 1) ? 0x10000u : 1u);
-                }
+    wk.xflag = __builtin_amdgcn_readfirstlane(jb->par[0]); wk.x0 = __builtin_amdgcn_readfirstlane(jb->par[1]);
+    wk.y0 = __builtin_amdgcn_readfirstlane(jb->par[2]); wk.dx = __builtin_amdgcn_readfirstlane(jb->par[3]);
+    wk.dy = __builtin_amdgcn_readfirstlane(jb->par[4]);
+    const int base = __builtin_amdgcn_readfirstlane(jb->par[5]);
+    uint64_t pat = 0;
+    for (int bb = part; bb < 64; bb += JOB_WORKERS) pat |= 1ull << bb;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int q = 0; q < LINE_NC; q++) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb->bits[k][q][0]);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb->bits[k][q][1]);
+            uint64_t m = (((uint64_t)hi << 32) | lo) & pat;
+            while (m) {
+                const int t = base + q * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                int j1, i1;
+                wk.at(t, k ? -1 : 1, j1, i1);
+                uint32_t widx, sh, over;
+                vote_bin(vl, (float)j1, (float)i1, widx, sh, over);
+                atomicSub(&vl.words[widx], vl.one << sh);
             }
         }
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicAdd(&jb->done, 1);
 }
 
 // wave 0: do its share of the job in flight (if any) and wait for the helpers
-__device__ __forceinline__ void job_finish(Jobs *jb, bool inflight, const Ppht &c, int lane) {
+__device__ __forceinline__ void job_finish(Jobs *jb, bool inflight, const VoteLane &vl, int lane) {
     if (!inflight) return;
-    job_work(jb, 0, c, lane);
-    while (*(volatile int *)&jb->done < JOB_WAVES) __builtin_amdgcn_s_sleep(1);
+    job_work(jb, 0, vl, lane);
+    while (*(volatile int *)&jb->done < JOB_WORKERS) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// helper wavefronts (part 1 and 2): serve every job until told to leave
-__device__ __forceinline__ void job_serve(Jobs *jb, int part, const Ppht &c, int lane) {
+// helper wavefronts (parts 1 .. JOB_WORKERS - 1): serve every job until told to leave
+__device__ __forceinline__ void job_serve(Jobs *jb, int part, const VoteLane &vl, int lane) {
     int seen = 0;
     for (;;) {
         int sq;
@@ -223,18 +269,27 @@ __device__ __forceinline__ void job_serve(Jobs *jb, int part, const Ppht &c, int
         if (sq < 0) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         seen = sq;
-        job_work(jb, part, c, lane);
+        job_work(jb, part, vl, lane);
     }
 }
+
+// What the caller needs to know about a line that was walked: its pixels are on `wk` at the steps
+// -end1 .. end0 (negative = the second direction).
+struct LineOut {
+    Walk wk;
+    int end0, end1;
+};
 
 // A point reached the threshold at angle max_n: walk the line both ways, decide whether it is long
 // enough, clear its mask bits and, if accepted, take its votes back and emit the segment.
 // (Inlined at its single call site per kernel so that every LDS access keeps its address space and the
-// constants stay in registers; the per-lane trig pair is read with v_readlane, not from memory.)
+// constants stay in registers.)
 // Returns (accepted ? 1 : 0) | jobs posted so far << 1 (segment number nseg is written if it fits).
 // jobseq is the caller's count of vote-removal jobs posted so far; it lives in registers, not LDS.
 template <bool LDS_STATE>
-__device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int i, int max_n, int nseg, Jobs *jb, int jobseq) {
+__device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int i, int max_n, int nseg, Jobs *jb, int jobseq,
+                                            const VoteLane &vl, LineOut &lo) {
+    constexpr int NC = LINE_NC;
     bool inflight = false;   // a vote-removal job of this line is with the helpers
     const AngleEntry e = c.tab[max_n];
     Walk wk;
@@ -242,115 +297,224 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
     if (e.xflag) { wk.x0 = j; wk.y0 = (i << 16) + 32768; wk.dx = e.dmaj; wk.dy = e.dmin; }
     else         { wk.x0 = (j << 16) + 32768; wk.y0 = i; wk.dx = e.dmin; wk.dy = e.dmaj; }
 
-    // The first NC chunks (64 steps each) of both directions are fetched in one go -- all mask words in
-    // flight together, one memory round trip for most lines -- and their ballots are kept: pass 2 needs
-    // the same bits (nothing else clears this line's pixels in between), so it reloads nothing.
-    constexpr int NC = 4;
-    uint64_t nzm[2][NC], inbm[2][NC];
-    {
+    // NC chunks (64 steps each) of both directions are fetched in one go: every load of a stage is
+    // issued before the first result is used (one LDS or memory round trip per stage, not per chunk).
+    // `want[k]` switches a finished direction off.  wword receives, per chunk, the LDS word of the
+    // lane's step (fast path; meaningful where the step's bit is set).
+    auto fetch = [&](int sbase, const bool (&want)[2], uint64_t (&nz)[2][NC], uint64_t (&inbm)[2][NC], uint32_t (&wword)[2][NC]) {
         uint64_t wv[2][NC];
         bool inb[2][NC];
         int sh[2][NC];
+        if constexpr (LDS_STATE) {
+            uint32_t ent[2][NC];
+            int wcol[2][NC];
 #pragma unroll
-        for (int k = 0; k < 2; k++)
+            for (int k = 0; k < 2; k++)
 #pragma unroll
-            for (int q = 0; q < NC; q++) {
-                int j1, i1;
-                wk.at(q * 64 + lane, k ? -1 : 1, j1, i1);
-                inb[k][q] = (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
-                sh[k][q] = j1 & 63;
-                wv[k][q] = inb[k][q] ? ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) : 0;
-            }
+                for (int q = 0; q < NC; q++) {
+                    int j1, i1;
+                    wk.at(sbase + q * 64 + lane, k ? -1 : 1, j1, i1);
+                    inb[k][q] = want[k] && (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
+                    sh[k][q] = j1 & 63;
+                    wcol[k][q] = j1 >> 6;
+                    const unsigned r = (unsigned)(i1 - c.ymin);
+                    ent[k][q] = c.rowtab[r < (unsigned)c.nrows ? r : 0u];
+                    if (r >= (unsigned)c.nrows) wcol[k][q] = -1;          // no points in that row
+                }
 #pragma unroll
-        for (int k = 0; k < 2; k++)
+            for (int k = 0; k < 2; k++)
 #pragma unroll
-            for (int q = 0; q < NC; q++) {
-                inbm[k][q] = __ballot(inb[k][q]);
-                nzm[k][q] = __ballot(inb[k][q] && ((wv[k][q] >> sh[k][q]) & 1));
-            }
-    }
-
-    // pass 1: how far the line reaches in each direction
-    int end_t[2];
+                for (int q = 0; q < NC; q++) {
+                    const uint32_t e = ent[k][q];
+                    const unsigned wi = (unsigned)wcol[k][q] - ((e >> 16) & 0xFFu);
+                    const bool in_span = wcol[k][q] >= 0 && wi < (e >> 24);
+                    wword[k][q] = in_span ? (e & 0xFFFFu) + wi : 0u;
+                    wv[k][q] = c.lmask[wword[k][q]];
+                    if (!in_span) sh[k][q] = -1;
+                }
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int sgn = k ? -1 : 1;
-        int last_t = 0;
-        bool done = false;
-        auto scan = [&](int base, uint64_t inb_m, uint64_t nz_m) {
-            const int first_oob = inb_m == ~0ull ? 64 : __builtin_ctzll(~inb_m);
-            if (first_oob < 64) nz_m &= (1ull << first_oob) - 1;
-            while (nz_m) {
-                int tt = base + __builtin_ctzll(nz_m);
-                if (tt > last_t + c.line_gap + 1) { done = true; break; }
-                last_t = tt;
-                nz_m &= nz_m - 1;
-            }
-            if (first_oob < 64 || base + 63 - last_t > c.line_gap) done = true;
-        };
+            for (int k = 0; k < 2; k++)
 #pragma unroll
-        for (int q = 0; q < NC; q++)
-            if (!done) scan(q * 64, inbm[k][q], nzm[k][q]);
-        for (int base = NC * 64; !done; base += 64) {   // rare: longer than NC chunks
-            int j1, i1;
-            wk.at(base + lane, sgn, j1, i1);
-            const bool inb = (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
-            bool bit = false;
-            if (inb) bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
-            scan(base, __ballot(inb), __ballot(bit));
+                for (int q = 0; q < NC; q++) {
+                    inbm[k][q] = __ballot(inb[k][q]);
+                    nz[k][q] = __ballot(inb[k][q] && sh[k][q] >= 0 && ((wv[k][q] >> (sh[k][q] & 63)) & 1));
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int q = 0; q < NC; q++) {
+                    int j1, i1;
+                    wk.at(sbase + q * 64 + lane, k ? -1 : 1, j1, i1);
+                    inb[k][q] = want[k] && (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
+                    sh[k][q] = j1 & 63;
+                    wword[k][q] = 0;
+                    wv[k][q] = inb[k][q] ? ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) : 0;
+                }
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int q = 0; q < NC; q++) {
+                    inbm[k][q] = __ballot(inb[k][q]);
+                    nz[k][q] = __ballot(inb[k][q] && ((wv[k][q] >> sh[k][q]) & 1));
+                }
         }
-        end_t[k] = last_t;
+    };
+
+#ifdef LC_STAMPS
+    long long ts0 = STAMP();
+#endif
+    // pass 1: how far the line reaches in each direction
+    int end_t[2] = {0, 0};
+    uint64_t nzm[2][NC];      // edge pixels of the first stretch; pass 2 needs the same bits again
+    uint32_t wword0[2][NC];   // and their LDS words
+    {
+        bool going[2] = {true, true};
+        for (int sbase = 0; going[0] || going[1]; sbase += NC * 64) {
+            uint64_t nz[2][NC], inbm[2][NC];
+            uint32_t ww[2][NC];
+            fetch(sbase, going, nz, inbm, ww);
+            if (sbase == 0) {
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+#pragma unroll
+                    for (int q = 0; q < NC; q++) { nzm[k][q] = nz[k][q]; wword0[k][q] = ww[k][q]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                int last_t = end_t[k];
+                bool done = !going[k];
+#pragma unroll
+                for (int q = 0; q < NC; q++) {
+                    if (done) continue;
+                    const int base = sbase + q * 64;
+                    uint64_t nz_m = nz[k][q];
+                    const uint64_t inb_m = inbm[k][q];
+                    const int first_oob = inb_m == ~0ull ? 64 : __builtin_ctzll(~inb_m);
+                    if (first_oob < 64) nz_m &= (1ull << first_oob) - 1;
+                    // OpenCV stops at the first edge pixel more than line_gap + 1 steps after the previous one.
+                    // All 64 steps at once: `reach` has the steps within that distance of an earlier edge pixel
+                    // (of this chunk, or of the last one before it); the first edge pixel outside it ends the line.
+                    if (nz_m) {
+                        const int G = c.line_gap + 1;
+                        uint64_t reach;
+                        if (G <= 0) {
+                            reach = 0;
+                        } else if (G >= 64) {
+                            reach = ~(nz_m ^ (nz_m - 1));            // everything above the lowest edge pixel
+                        } else {
+                            reach = nz_m << 1;                       // distances 1 .. span
+                            int span = 1;
+                            while (span * 2 <= G) { reach |= reach << span; span *= 2; }
+                            if (span < G) reach |= reach << (G - span);
+                        }
+                        const int from_last = G - (base - last_t);   // steps of this chunk still within reach of last_t, minus 1
+                        if (from_last >= 63) reach = ~0ull;
+                        else if (from_last >= 0) reach |= (2ull << from_last) - 1;
+                        const uint64_t fail = nz_m & ~reach;
+                        if (fail) {
+                            done = true;
+                            nz_m &= (fail & (0 - fail)) - 1;         // the edge pixels before the first failure
+                        }
+                        if (nz_m) last_t = base + 63 - __builtin_clzll(nz_m);
+                    }
+                    if (first_oob < 64 || base + 63 - last_t > c.line_gap) done = true;
+                }
+                end_t[k] = last_t;
+                going[k] = !done;
+            }
+        }
     }
     int ex0, ey0, ex1, ey1;
     wk.at(end_t[0], 1, ex0, ey0);
     wk.at(end_t[1], -1, ex1, ey1);
     const bool good = abs(ex1 - ex0) >= c.line_length || abs(ey1 - ey0) >= c.line_length;
+    lo.wk = wk; lo.end0 = end_t[0]; lo.end1 = end_t[1];
+#ifdef LC_STAMPS
+    long long ts1 = STAMP();
+#endif
 
     // pass 2: clear the mask along the line; an accepted line takes its votes back
+    const int end_max = max(end_t[0], end_t[1]);
+    for (int sbase = 0; sbase <= end_max; sbase += NC * 64) {
+        uint64_t bm[2][NC];
+        uint32_t ww[2][NC];
+        if (sbase == 0) {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int sgn = k ? -1 : 1;
-        for (int base = 0; base <= end_t[k]; base += 64) {
-            const int t = base + lane;
-            int j1, i1;
-            wk.at(t, sgn, j1, i1);
-            uint64_t bm;
-            if (base < NC * 64) {
-                bm = base == 0 ? nzm[k][0] : (base == 64 ? nzm[k][1] : (base == 128 ? nzm[k][2] : nzm[k][3]));
-            } else {
-                bool bit = false;
-                if (t <= end_t[k]) bit = (ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) >> (j1 & 63)) & 1;
-                bm = __ballot(bit);
-            }
-            const int nvalid = end_t[k] - base + 1;                     // steps of this chunk on the line
-            if (nvalid < 64) bm &= (1ull << nvalid) - 1;
-            if (k == 1 && base == 0) bm &= ~1ull;                       // t = 0 belongs to direction 0
-            const bool bit = (bm >> lane) & 1;
-            if constexpr (LDS_STATE) {
-                if (good && bm) {   // hand the chunk's vote removal to the workgroup, keep walking
-                    job_finish(jb, inflight, c, lane);       // one job in flight at a time
-                    ++jobseq;
-                    if (lane == 0) {
-                        jb->par[0] = wk.xflag; jb->par[1] = wk.x0; jb->par[2] = wk.y0; jb->par[3] = wk.dx; jb->par[4] = wk.dy;
-                        jb->par[5] = sgn; jb->par[6] = base;
-                        jb->par[7] = (int)(uint32_t)bm; jb->par[8] = (int)(uint32_t)(bm >> 32);
-                        jb->done = 0;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        *(volatile int *)&jb->seq = jobseq;
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int q = 0; q < NC; q++) { bm[k][q] = nzm[k][q]; ww[k][q] = wword0[k][q]; }
+        } else {
+            const bool want[2] = {sbase <= end_t[0], sbase <= end_t[1]};
+            uint64_t inbm[2][NC];
+            fetch(sbase, want, bm, inbm, ww);
+        }
+        uint64_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const int base = sbase + q * 64;
+                const int nvalid = end_t[k] - base + 1;                 // steps of this chunk on the line
+                uint64_t m = bm[k][q];
+                if (nvalid <= 0) m = 0;
+                else if (nvalid < 64) m &= (1ull << nvalid) - 1;
+                if (k == 1 && base == 0) m &= ~1ull;                    // t = 0 belongs to direction 0
+                bm[k][q] = m;
+                any |= m;
+                if ((m >> lane) & 1) {
+                    int j1, i1;
+                    wk.at(base + lane, k ? -1 : 1, j1, i1);
+                    if constexpr (LDS_STATE) {
+                        atomicAnd((unsigned long long *)(c.lmask + ww[k][q]), ~(1ull << (j1 & 63)));
+                    } else {
+                        atomicAnd((unsigned long long *)(c.mask + (size_t)i1 * c.TX + (j1 >> 6)), ~(1ull << (j1 & 63)));
                     }
-                    inflight = true;
-                }
-            } else if (bit && good) {
-                for (int nn = 0; nn < c.numangle; nn++) {
-                    int r = rho_bin(j1, i1, c.tab[nn].c, c.tab[nn].s, c.half);
-                    if ((unsigned)r < (unsigned)c.numrho) atomicSub(&c.acc[(size_t)nn * c.numrho + r], 1);
+                    if constexpr (!LDS_STATE) {
+                        if (good) {
+                            for (int nn = 0; nn < c.numangle; nn++) {
+                                int r = rho_bin(j1, i1, c.tab[nn].c, c.tab[nn].s, c.half);
+                                if ((unsigned)r < (unsigned)c.numrho) atomicSub(&c.acc[(size_t)nn * c.numrho + r], 1);
+                            }
+                        }
+                    }
                 }
             }
-            if (bit) atomicAnd((unsigned long long *)(c.mask + (size_t)i1 * c.TX + (j1 >> 6)), ~(1ull << (j1 & 63)));
+        if constexpr (LDS_STATE) {
+            if (good && any) {   // hand the stretch's vote removal to the workgroup
+                job_finish(jb, inflight, vl, lane);       // one job in flight at a time
+                ++jobseq;
+                if (lane == 0) {
+                    jb->par[0] = wk.xflag; jb->par[1] = wk.x0; jb->par[2] = wk.y0; jb->par[3] = wk.dx; jb->par[4] = wk.dy;
+                    jb->par[5] = sbase;
+#pragma unroll
+                    for (int k = 0; k < 2; k++)
+#pragma unroll
+                        for (int q = 0; q < NC; q++) {
+                            jb->bits[k][q][0] = (uint32_t)bm[k][q];
+                            jb->bits[k][q][1] = (uint32_t)(bm[k][q] >> 32);
+                        }
+                    jb->done = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    *(volatile int *)&jb->seq = jobseq;
+                }
+                inflight = true;
+            }
         }
     }
-    if constexpr (LDS_STATE) job_finish(jb, inflight, c, lane);   // every vote is back before the next pick
+#ifdef LC_STAMPS
+    long long ts2 = STAMP();
+#endif
+    if constexpr (LDS_STATE) job_finish(jb, inflight, vl, lane);   // every vote is back before the next pick
+#ifdef LC_STAMPS
+    long long ts3 = STAMP();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LC_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+        g_dbg[0] += ts1 - ts0; g_dbg[1] += ts2 - ts1; g_dbg[2] += ts3 - ts2; g_dbg[3] += STAMP() - ts3;
+    }
+#endif
     if (good && lane == 0 && nseg < c.seg_cap) {
         c.seg[4 * nseg + 0] = ex0; c.seg[4 * nseg + 1] = ey0;
         c.seg[4 * nseg + 2] = ex1; c.seg[4 * nseg + 3] = ey1;
@@ -415,7 +579,9 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restric
         const int max_n = 0x7FFFFFFF - (int)(unsigned)(best & 0xFFFFFFFFll);
         const int max_val = (int)((best - (long long)(0x7FFFFFFF - max_n)) / 4294967296ll);
         if (max_val < threshold) continue;
-        if (extract_line<false>(c, lane, j, i, max_n, nseg, nullptr, 0) & 1) nseg++;
+        VoteLane unused_vl{};
+        LineOut unused_lo;
+        if (extract_line<false>(c, lane, j, i, max_n, nseg, nullptr, 0, unused_vl, unused_lo) & 1) nseg++;
     }
     if (lane == 0) seg_count[f] = nseg;
 }
@@ -426,16 +592,19 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restric
 //   point goes to the slot the swap frees, so the array read from the back is the order);
 //   wavefront 0 follows it, with the mask words of the next four points in flight, votes in LDS with
 //   one angle per lane and reduces the maximum with DPP.
-__global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__restrict__ nz_all, int nz_cap,
+__global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_t *__restrict__ nz_all, int nz_cap,
                                                    const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
                                                    const AngleEntry *__restrict__ tab, int numangle, int numrho,
                                                    int threshold, int line_length, int line_gap,
                                                    int32_t *__restrict__ seg_all, int seg_cap, int *__restrict__ seg_count,
                                                    int *__restrict__ status, int *__restrict__ fallback, int lds_points,
-                                                   const uint32_t *__restrict__ rng_out) {
-    extern __shared__ int16_t lds16[];
+                                                   const uint32_t *__restrict__ rng_out, int lds_bytes) {
+    extern __shared__ __align__(16) uint32_t lds32[];
     __shared__ int progress;
     __shared__ Jobs jobs;
+    __shared__ int s_xmin, s_xmax, s_maskwords, s_accbins;
+    __shared__ int s_part[PPHT_THREADS];
+    __shared__ uint32_t a_base[64], a_rfix[64], a_wid[64];
     // this kernel is a few latency-bound wavefronts per CU: let them issue ahead of the streaming
     // kernels of other batches that share the SIMDs
     __builtin_amdgcn_s_setprio(3);
@@ -444,6 +613,10 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
     const int n = npoints[f];
     if (n > nz_cap) {
         if (tid == 0) { seg_count[f] = 0; fallback[f] = 0; atomicOr(status, 1); }
+        return;
+    }
+    if (n == 0) {
+        if (tid == 0) { seg_count[f] = 0; fallback[f] = 0; }
         return;
     }
     if (n > lds_points || n >= LDS_BIAS) {   // biased 16-bit bins hold counts in (-LDS_BIAS, LDS_BIAS)
@@ -455,25 +628,124 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
     c.threshold = threshold; c.line_length = line_length; c.line_gap = line_gap; c.seg_cap = seg_cap;
     c.mask = rowplane + (size_t)f * g.rowplane_words();
     c.tab = tab; c.acc = nullptr;
-    c.lacc = lds16;
     c.seg = seg_all + (size_t)f * seg_cap * 4;
-    uint32_t *lnz = reinterpret_cast<uint32_t *>(lds16 + (((size_t)numangle * numrho + 1) & ~(size_t)1));
+
+    // ---- set-up: everything the loop touches moves into LDS ------------------------------------
+    // layout: [points n][row table nrows][accumulator][mask spans]
+    // The points arrive sorted by row, then column.  Only bins a pixel of the points' bounding box can
+    // reach are kept of every angle's accumulator row, and only the words between the first and the
+    // last point of every row of the mask -- together a fraction of the full arrays.
+    uint32_t *lnz = lds32;
+    const int ymin = (int)(nz[0] >> 16), ymax = (int)(nz[n - 1] >> 16);
+    const int nrows = ymax - ymin + 1;
+    uint32_t *rowtab = lds32 + n;
+    if (tid == 0) {
+        progress = 0; fallback[f] = 0;
+        jobs.seq = 0; jobs.done = 0;
+        s_xmin = INT_MAX; s_xmax = 0;
+    }
+    for (int r = tid; r < nrows; r += PPHT_THREADS) rowtab[r] = 0;
+    __syncthreads();
     {
-        uint32_t *z = reinterpret_cast<uint32_t *>(lds16);
-        const int zw = (numangle * numrho + 1) / 2;
-        for (int i = tid; i < zw; i += 256) z[i] = (uint32_t)LDS_BIAS * 0x10001u;
-        for (int i = tid; i < n; i += 256) lnz[i] = nz[i];
-        if (tid == 0) {
-            progress = 0; fallback[f] = 0;
-            jobs.seq = 0; jobs.done = 0;
+        int xmin = INT_MAX, xmax = 0;
+        for (int i = tid; i < n; i += PPHT_THREADS) {
+            const uint32_t pt = nz[i];
+            lnz[i] = pt;
+            const int x = (int)(pt & 0xFFFF), y = (int)(pt >> 16);
+            xmin = min(xmin, x); xmax = max(xmax, x);
+            // first / last point of its row: they bound the row's span (bit 0 marks a row that has points)
+            const bool first = i == 0 || (int)(nz[i - 1] >> 16) != y;
+            const bool last = i == n - 1 || (int)(nz[i + 1] >> 16) != y;
+            if (first) atomicOr(&rowtab[y - ymin], 1u | ((uint32_t)(x >> 6) << 16));
+            if (last) atomicOr(&rowtab[y - ymin], (uint32_t)(x >> 6) << 24);
         }
-        if (tid < 64) { jobs.tc[tid] = tid < numangle ? tab[tid].c : 0.f; jobs.ts[tid] = tid < numangle ? tab[tid].s : 0.f; }
+        atomicMin(&s_xmin, xmin);
+        atomicMax(&s_xmax, xmax);
     }
     __syncthreads();
-    float my_c = 0.f, my_s = 0.f;   // lane l holds the trig pair of angle l
-    if (lane < numangle) { my_c = tab[lane].c; my_s = tab[lane].s; }
+    {   // exclusive scan of the span lengths over the rows -> first LDS word of every row
+        const int per = (nrows + PPHT_THREADS - 1) / PPHT_THREADS;
+        const int r0 = tid * per, r1 = min(nrows, r0 + per);
+        int sum = 0;
+        for (int r = r0; r < r1; r++) {
+            const uint32_t e = rowtab[r];
+            if (e & 1u) sum += (int)(e >> 24) - (int)((e >> 16) & 0xFFu) + 1;
+        }
+        s_part[tid] = sum;
+        __syncthreads();
+        for (int d = 1; d < PPHT_THREADS; d <<= 1) {
+            const int v = tid >= d ? s_part[tid - d] : 0;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        int off = s_part[tid] - sum;
+        for (int r = r0; r < r1; r++) {
+            const uint32_t e = rowtab[r];
+            uint32_t out = 0;
+            if (e & 1u) {
+                const uint32_t w0 = (e >> 16) & 0xFFu, nw = (e >> 24) - w0 + 1;
+                out = ((uint32_t)off & 0xFFFFu) | (w0 << 16) | (nw << 24);
+                off += (int)nw;
+            }
+            rowtab[r] = out;
+        }
+        if (tid == PPHT_THREADS - 1) s_maskwords = s_part[tid];
+    }
+    if (wave == 0) {   // reachable bins of every angle: the extremes are at the corners of the bounding box
+        const int xmin = s_xmin, xmax = s_xmax;
+        float ac = 0.f, as = 0.f;
+        if (lane < numangle) { ac = tab[lane].c; as = tab[lane].s; }
+        auto rbin = [&](int x, int y) {
+            const float v = __fadd_rn(__fmul_rn((float)x, ac), __fmul_rn((float)y, as));
+            return (int)(__float_as_uint(__fadd_rn(v, ROUND_MAGIC)) - 0x4B400000u) + c.half;
+        };
+        const int b0 = rbin(xmin, ymin), b1 = rbin(xmax, ymin), b2 = rbin(xmin, ymax), b3 = rbin(xmax, ymax);
+        const int rmin = min(min(b0, b1), min(b2, b3)), rmax = max(max(b0, b1), max(b2, b3));
+        const int nb = lane < numangle ? rmax - rmin + 1 : 0;
+        int incl = nb;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        a_base[lane] = lane < numangle ? (uint32_t)(incl - nb) : 0u;
+        a_wid[lane] = lane < numangle ? (uint32_t)(rmax - rmin) : 0u;
+        a_rfix[lane] = (uint32_t)(c.half - rmin) - 0x4B400000u;
+        if (lane == 63) s_accbins = incl;
+        // a table whose bins leave [0, numrho) is not OpenCV's: refuse
+        if (lane < numangle && (rmin < 0 || rmax >= numrho)) atomicOr(status, 2);
+    }
+    __syncthreads();
+    const int accbins = s_accbins, maskwords = s_maskwords;
+    const size_t acc_off = ((size_t)(n + nrows) + 1) & ~(size_t)1;                 // in 32-bit words, 8-byte aligned
+    const size_t acc_words = ((size_t)accbins + 1) / 2;
+    const size_t mask_off = (acc_off + acc_words + 1) & ~(size_t)1;
+    if ((mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes || maskwords > 0xFFFF) {
+        if (tid == 0) fallback[f] = 1;   // does not fit the CU's LDS: the general kernel takes the frame
+        return;
+    }
+    c.lacc = reinterpret_cast<int16_t *>(lds32 + acc_off);
+    c.lmask = reinterpret_cast<uint64_t *>(lds32 + mask_off);
+    c.rowtab = rowtab; c.ymin = ymin; c.nrows = nrows;
+    for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[acc_off + i] = (uint32_t)LDS_BIAS * 0x10001u;
+    for (int r = wave; r < nrows; r += PPHT_THREADS / 64) {
+        const uint32_t e = rowtab[r];
+        const int nw = (int)(e >> 24);
+        const uint64_t *src = c.mask + (size_t)(ymin + r) * c.TX + ((e >> 16) & 0xFFu);
+        for (int l = lane; l < nw; l += 64) c.lmask[(e & 0xFFFFu) + l] = src[l];
+    }
+    __syncthreads();
+    // lane l votes for angle l; lanes past the last angle add zero to a harmless bin instead of branching
+    VoteLane vl;
+    vl.c = vl.s = 0.f;
+    if (lane < numangle) { vl.c = tab[lane].c; vl.s = tab[lane].s; }
+    vl.base = a_base[lane];
+    vl.one = lane < numangle ? 1u : 0u;
+    vl.rfix = a_rfix[lane];
+    vl.wid = a_wid[lane];
+    vl.words = reinterpret_cast<uint32_t *>(c.lacc);
     if (wave >= 2) {                // helpers: vote removal for accepted lines
-        job_serve(&jobs, wave - 1, c, lane);
+        job_serve(&jobs, wave - 1, vl, lane);
         return;
     }
 
@@ -511,27 +783,20 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
     // consumer.  Points are taken 64 at a time: lane t loads point k + t and its mask word, a ballot
     // says which are still alive (dead ones cost nothing).  Alive points vote Q at a time with
     // returning LDS atomics issued back to back; if one of them reaches the threshold the votes of the
-    // later ones are taken back, the line is extracted and the batch restarts behind that point, so
-    // every count any point sees is the one OpenCV's strictly sequential loop would see.
-    // The vote itself is straight-line code: a missing point of a short group and the lanes past the
-    // last angle add zero to a harmless bin instead of branching around the atomic.
-    uint32_t *words = reinterpret_cast<uint32_t *>(c.lacc);
-    const uint32_t lane_base = lane < numangle ? (uint32_t)(lane * numrho) : (uint32_t)(lane * 2);
-    const uint32_t lane_one = lane < numangle ? 1u : 0u;
+    // later ones are taken back and the line is extracted.  The batch then goes on behind that point
+    // without touching memory: a batch point died iff it lies on the walked stretch of the line, which
+    // every lane checks for its own point.  Every count any point sees is therefore the one OpenCV's
+    // strictly sequential loop would see.
+    uint32_t *words = vl.words;
     const uint64_t lanes_mask = numangle >= 64 ? ~0ull : ((1ull << numangle) - 1);
     // count after the vote >= threshold  <=>  biased 16-bit bin before the vote >= threshold - 1 + bias
     const uint32_t thr_b = (uint32_t)min(max((long long)threshold - 1 + LDS_BIAS, 0ll), 0x10000ll);
-    // cvRound of |v| < 2^22: adding 1.5 * 2^23 rounds v half-to-even into the low mantissa bits
-    constexpr float ROUND_MAGIC = 12582912.0f;
-    const uint32_t rfix = (uint32_t)c.half - 0x4B400000u;
-    const uint32_t rho_last = (uint32_t)(numrho - 1);
-    uint32_t r_seen = 0;   // largest (unsigned) bin number any vote produced; out of range means a bad table
+    uint32_t r_over = 0;   // non-zero if a vote ever left its angle's reachable range (a bad table)
     int nseg = 0, jobseq = 0;
 #ifdef LC_STAMPS
     long long t_wait = 0, t_vote = 0, t_line = 0, n_alive = 0, n_line = 0, tc0 = STAMP();
 #endif
-    int k = 0;
-    while (k < n) {
+    for (int k = 0; k < n; k += 64) {
         const int m = min(64, n - k);
 #ifdef LC_STAMPS
         long long tw = STAMP();
@@ -542,17 +807,18 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
         bool alive_l = false;
         if (lane < m) {
             ptv = lnz[n - 1 - (k + lane)];
-            const uint64_t w = ld_l2(c.mask + (size_t)(ptv >> 16) * c.TX + ((ptv & 0xFFFF) >> 6));
-            alive_l = (w >> (ptv & 63)) & 1;
+            uint32_t widx;
+            alive_l = lds_mask_bit(c, (int)(ptv & 0xFFFF), (int)(ptv >> 16), widx);
         }
-        const float fjv = (float)(ptv & 0xFFFF), fiv = (float)(ptv >> 16);
+        const int pjv = (int)(ptv & 0xFFFF), piv = (int)(ptv >> 16);
+        const float fjv = (float)pjv, fiv = (float)piv;
         uint64_t alive = __ballot(alive_l);
 #ifdef LC_STAMPS
         t_wait += STAMP() - tw;
 #endif
-        bool restarted = false;
-        while (alive && !restarted) {
+        while (alive) {
             constexpr int Q = PPHT_Q;
+            const uint64_t alive0 = alive;
             int tq[Q];
             uint32_t inc[Q], widx[Q], sh[Q], old[Q];
             uint64_t vmask[Q];
@@ -567,14 +833,10 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
                 vmask[q] = valid ? lanes_mask : 0ull;
                 const float fj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), tq[q]));
                 const float fi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), tq[q]));
-                const float v = __fadd_rn(__fmul_rn(fj, my_c), __fmul_rn(fi, my_s));
-                uint32_t r = __float_as_uint(__fadd_rn(v, ROUND_MAGIC)) + rfix;   // cvRound(v) + half
-                r_seen = max(r_seen, r);
-                r = min(r, rho_last);
-                const uint32_t a = lane_base + r;
-                sh[q] = (a & 1u) << 4;               // two biased 16-bit bins per word
-                widx[q] = a >> 1;
-                inc[q] = (valid ? lane_one : 0u) << sh[q];
+                uint32_t over;
+                vote_bin(vl, fj, fi, widx[q], sh[q], over);
+                r_over |= over;
+                inc[q] = (valid ? vl.one : 0u) << sh[q];
                 old[q] = atomicAdd(&words[widx[q]], inc[q]);
             }
             // a point starts a line iff some angle's count reaches the threshold: one compare and a ballot
@@ -612,19 +874,23 @@ __global__ __launch_bounds__(256) void k_ppht_fast(Geo g, const uint32_t *__rest
                 long long tl = STAMP();
                 n_line++;
 #endif
-                const int lr = extract_line<true>(c, lane, (int)(hpt & 0xFFFF), (int)(hpt >> 16), max_n, nseg, &jobs, jobseq);
+                LineOut lo;
+                const int lr = extract_line<true>(c, lane, (int)(hpt & 0xFFFF), (int)(hpt >> 16), max_n, nseg, &jobs, jobseq, vl, lo);
                 jobseq = lr >> 1;
                 if (lr & 1) nseg++;
+                // which points of the batch the line took: signed step of the lane's point along the major axis
+                int st, minor;
+                if (lo.wk.xflag) { st = (pjv - lo.wk.x0) * lo.wk.dx; minor = ((lo.wk.y0 + st * lo.wk.dy) >> 16) - piv; }
+                else             { st = (piv - lo.wk.y0) * lo.wk.dy; minor = ((lo.wk.x0 + st * lo.wk.dx) >> 16) - pjv; }
+                const bool on_line = minor == 0 && st <= lo.end0 && st >= -lo.end1;
+                alive = alive0 & ~((2ull << ht) - 1) & ~__ballot(on_line);
 #ifdef LC_STAMPS
                 t_line += STAMP() - tl;
 #endif
-                k += ht + 1;
-                restarted = true;
             }
         }
-        if (!restarted) k += m;
     }
-    if (__ballot(r_seen > rho_last) != 0 && lane == 0) atomicOr(status, 2);
+    if (__ballot(r_over != 0 && lane < numangle) != 0 && lane == 0) atomicOr(status, 2);
     if (lane == 0) *(volatile int *)&jobs.seq = -1;   // helpers leave
     if (lane == 0) seg_count[f] = nseg;
 #ifdef LC_STAMPS
@@ -671,22 +937,22 @@ void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoint
                  const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
                  int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, int *fallback,
                  const uint32_t *rng_out, int rng_len, hipStream_t st) {
-    // fast path: int16 accumulator + point list in LDS (160 KiB per CU); frames that do not fit fall back
-    const size_t acc_bytes = (((size_t)numangle * numrho + 1) & ~(size_t)1) * 2;
-    const size_t lds_max = 160 * 1024 - 1024;   // minus the kernel's static LDS (job block, progress word)
+    // fast path: points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not
+    // fit (the kernel decides, per frame) is flagged for the general kernel.  The kernel gets 144 of the
+    // CU's 160 KiB: the rest stays free for its own static tables and for the small kernels of the next
+    // batch (hysteresis closure, vote) that run beside it.
     bool fast = false;
-    if (numangle <= 64 && acc_bytes + 4096 <= lds_max) {
-        // the point list takes at most 32 KiB so that a few KiB of every CU's LDS stay free for the small
-        // kernels of the next batch (hysteresis closure, vote) running beside this one
-        const int lds_points = std::min(std::min((int)((lds_max - acc_bytes) / 4), rng_len), 8192);
-        const size_t lds = acc_bytes + 4 * (size_t)lds_points;
-        static size_t fast_attr = 0;
-        if (lds > fast_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            fast_attr = lds;
+    if (numangle <= 64 && g.W <= 16320) {
+        const int lds_bytes = 144 * 1024;
+        const int lds_points = std::min(rng_len, LDS_BIAS - 1);
+        static bool fast_attr = false;
+        if (!fast_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_fast), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            fast_attr = true;
         }
-        hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(256), lds, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
-                           numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, fallback, lds_points, rng_out);
+        hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(PPHT_THREADS), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+                           numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, fallback, lds_points, rng_out,
+                           lds_bytes);
         fast = true;
     }
     hipLaunchKernelGGL(k_ppht_general, dim3(nframes), dim3(256), 0, st, g, nz, nz_cap, npoints, rowplane, tab, numangle, numrho,
