@@ -273,6 +273,73 @@ __device__ __forceinline__ void job_serve(Jobs *jb, int part, const VoteLane &vl
     }
 }
 
+// N chunks (64 steps each) of both directions of a walk, fetched in one go: every load of a stage is
+// issued before the first result is used (one LDS or memory round trip per stage, not per chunk).
+// want[k] switches a finished direction off.  nz gets the ballots of the edge pixels, inbm of the steps
+// inside the image; wword, per chunk, the LDS word of the lane's step (fast path; meaningful where the
+// step's bit is set).
+template <bool LDS_STATE, int N>
+__device__ __forceinline__ void fetch_chunks(const Ppht &c, const Walk &wk, int lane, int sbase, const bool (&want)[2],
+                                             uint64_t (&nz)[2][N], uint64_t (&inbm)[2][N], uint32_t (&wword)[2][N]) {
+    uint64_t wv[2][N];
+    bool inb[2][N];
+    int sh[2][N];
+    if constexpr (LDS_STATE) {
+        uint32_t ent[2][N];
+        int wcol[2][N];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                int j1, i1;
+                wk.at(sbase + q * 64 + lane, k ? -1 : 1, j1, i1);
+                inb[k][q] = want[k] && (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
+                sh[k][q] = j1 & 63;
+                wcol[k][q] = j1 >> 6;
+                const unsigned r = (unsigned)(i1 - c.ymin);
+                ent[k][q] = c.rowtab[r < (unsigned)c.nrows ? r : 0u];
+                if (r >= (unsigned)c.nrows) wcol[k][q] = -1;          // no points in that row
+            }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                const uint32_t e = ent[k][q];
+                const unsigned wi = (unsigned)wcol[k][q] - ((e >> 16) & 0xFFu);
+                const bool in_span = wcol[k][q] >= 0 && wi < (e >> 24);
+                wword[k][q] = in_span ? (e & 0xFFFFu) + wi : 0u;
+                wv[k][q] = c.lmask[wword[k][q]];
+                if (!in_span) sh[k][q] = -1;
+            }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                inbm[k][q] = __ballot(inb[k][q]);
+                nz[k][q] = __ballot(inb[k][q] && sh[k][q] >= 0 && ((wv[k][q] >> (sh[k][q] & 63)) & 1));
+            }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                int j1, i1;
+                wk.at(sbase + q * 64 + lane, k ? -1 : 1, j1, i1);
+                inb[k][q] = want[k] && (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
+                sh[k][q] = j1 & 63;
+                wword[k][q] = 0;
+                wv[k][q] = inb[k][q] ? ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) : 0;
+            }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                inbm[k][q] = __ballot(inb[k][q]);
+                nz[k][q] = __ballot(inb[k][q] && ((wv[k][q] >> sh[k][q]) & 1));
+            }
+    }
+}
+
 // What the caller needs to know about a line that was walked: its pixels are on `wk` at the steps
 // -end1 .. end0 (negative = the second direction).
 struct LineOut {
@@ -297,132 +364,78 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
     if (e.xflag) { wk.x0 = j; wk.y0 = (i << 16) + 32768; wk.dx = e.dmaj; wk.dy = e.dmin; }
     else         { wk.x0 = (j << 16) + 32768; wk.y0 = i; wk.dx = e.dmin; wk.dy = e.dmaj; }
 
-    // NC chunks (64 steps each) of both directions are fetched in one go: every load of a stage is
-    // issued before the first result is used (one LDS or memory round trip per stage, not per chunk).
-    // `want[k]` switches a finished direction off.  wword receives, per chunk, the LDS word of the
-    // lane's step (fast path; meaningful where the step's bit is set).
-    auto fetch = [&](int sbase, const bool (&want)[2], uint64_t (&nz)[2][NC], uint64_t (&inbm)[2][NC], uint32_t (&wword)[2][NC]) {
-        uint64_t wv[2][NC];
-        bool inb[2][NC];
-        int sh[2][NC];
-        if constexpr (LDS_STATE) {
-            uint32_t ent[2][NC];
-            int wcol[2][NC];
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-#pragma unroll
-                for (int q = 0; q < NC; q++) {
-                    int j1, i1;
-                    wk.at(sbase + q * 64 + lane, k ? -1 : 1, j1, i1);
-                    inb[k][q] = want[k] && (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
-                    sh[k][q] = j1 & 63;
-                    wcol[k][q] = j1 >> 6;
-                    const unsigned r = (unsigned)(i1 - c.ymin);
-                    ent[k][q] = c.rowtab[r < (unsigned)c.nrows ? r : 0u];
-                    if (r >= (unsigned)c.nrows) wcol[k][q] = -1;          // no points in that row
-                }
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-#pragma unroll
-                for (int q = 0; q < NC; q++) {
-                    const uint32_t e = ent[k][q];
-                    const unsigned wi = (unsigned)wcol[k][q] - ((e >> 16) & 0xFFu);
-                    const bool in_span = wcol[k][q] >= 0 && wi < (e >> 24);
-                    wword[k][q] = in_span ? (e & 0xFFFFu) + wi : 0u;
-                    wv[k][q] = c.lmask[wword[k][q]];
-                    if (!in_span) sh[k][q] = -1;
-                }
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-#pragma unroll
-                for (int q = 0; q < NC; q++) {
-                    inbm[k][q] = __ballot(inb[k][q]);
-                    nz[k][q] = __ballot(inb[k][q] && sh[k][q] >= 0 && ((wv[k][q] >> (sh[k][q] & 63)) & 1));
-                }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-#pragma unroll
-                for (int q = 0; q < NC; q++) {
-                    int j1, i1;
-                    wk.at(sbase + q * 64 + lane, k ? -1 : 1, j1, i1);
-                    inb[k][q] = want[k] && (unsigned)j1 < (unsigned)c.W && (unsigned)i1 < (unsigned)c.H;
-                    sh[k][q] = j1 & 63;
-                    wword[k][q] = 0;
-                    wv[k][q] = inb[k][q] ? ld_l2(c.mask + (size_t)i1 * c.TX + (j1 >> 6)) : 0;
-                }
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-#pragma unroll
-                for (int q = 0; q < NC; q++) {
-                    inbm[k][q] = __ballot(inb[k][q]);
-                    nz[k][q] = __ballot(inb[k][q] && ((wv[k][q] >> sh[k][q]) & 1));
-                }
-        }
-    };
-
 #ifdef LC_STAMPS
     long long ts0 = STAMP();
 #endif
-    // pass 1: how far the line reaches in each direction
+    // pass 1: how far the line reaches in each direction.  With the mask in LDS a round trip is cheap, so
+    // the walk goes chunk by chunk and stops early (most candidate lines are short); from memory it takes
+    // NC chunks per round trip.  The ballots of the first NC chunks are kept: pass 2 needs them again.
+    constexpr int NG = LDS_STATE ? 1 : NC;
     int end_t[2] = {0, 0};
-    uint64_t nzm[2][NC];      // edge pixels of the first stretch; pass 2 needs the same bits again
-    uint32_t wword0[2][NC];   // and their LDS words
+    uint64_t nzm[2][NC] = {};
+    uint32_t wword0[2][NC] = {};
     {
         bool going[2] = {true, true};
-        for (int sbase = 0; going[0] || going[1]; sbase += NC * 64) {
-            uint64_t nz[2][NC], inbm[2][NC];
-            uint32_t ww[2][NC];
-            fetch(sbase, going, nz, inbm, ww);
-            if (sbase == 0) {
+        // OpenCV stops at the first edge pixel more than line_gap + 1 steps after the previous one.
+        // All 64 steps at once: `reach` has the steps within that distance of an earlier edge pixel (of
+        // this chunk, or of the last one before it); the first edge pixel outside it ends the line.
+        auto scan = [&](int k, int base, uint64_t nz_m, uint64_t inb_m) {
+            int last_t = end_t[k];
+            const int first_oob = inb_m == ~0ull ? 64 : __builtin_ctzll(~inb_m);
+            if (first_oob < 64) nz_m &= (1ull << first_oob) - 1;
+            bool done = false;
+            if (nz_m) {
+                const int G = c.line_gap + 1;
+                uint64_t reach;
+                if (G <= 0) {
+                    reach = 0;
+                } else if (G >= 64) {
+                    reach = ~(nz_m ^ (nz_m - 1));            // everything above the lowest edge pixel
+                } else {
+                    reach = nz_m << 1;                       // distances 1 .. span
+                    int span = 1;
+                    while (span * 2 <= G) { reach |= reach << span; span *= 2; }
+                    if (span < G) reach |= reach << (G - span);
+                }
+                const int from_last = G - (base - last_t);   // last step of this chunk still within reach of last_t
+                if (from_last >= 63) reach = ~0ull;
+                else if (from_last >= 0) reach |= (2ull << from_last) - 1;
+                const uint64_t fail = nz_m & ~reach;
+                if (fail) {
+                    done = true;
+                    nz_m &= (fail & (0 - fail)) - 1;         // the edge pixels before the first failure
+                }
+                if (nz_m) last_t = base + 63 - __builtin_clzll(nz_m);
+            }
+            if (first_oob < 64 || base + 63 - last_t > c.line_gap) done = true;
+            end_t[k] = last_t;
+            if (done) going[k] = false;
+        };
+#pragma unroll
+        for (int g0 = 0; g0 < NC; g0 += NG) {
+            if (going[0] || going[1]) {
+                uint64_t nz[2][NG], inbm[2][NG];
+                uint32_t ww[2][NG];
+                fetch_chunks<LDS_STATE, NG>(c, wk, lane, g0 * 64, going, nz, inbm, ww);
 #pragma unroll
                 for (int k = 0; k < 2; k++)
 #pragma unroll
-                    for (int q = 0; q < NC; q++) { nzm[k][q] = nz[k][q]; wword0[k][q] = ww[k][q]; }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                int last_t = end_t[k];
-                bool done = !going[k];
-#pragma unroll
-                for (int q = 0; q < NC; q++) {
-                    if (done) continue;
-                    const int base = sbase + q * 64;
-                    uint64_t nz_m = nz[k][q];
-                    const uint64_t inb_m = inbm[k][q];
-                    const int first_oob = inb_m == ~0ull ? 64 : __builtin_ctzll(~inb_m);
-                    if (first_oob < 64) nz_m &= (1ull << first_oob) - 1;
-                    // OpenCV stops at the first edge pixel more than line_gap + 1 steps after the previous one.
-                    // All 64 steps at once: `reach` has the steps within that distance of an earlier edge pixel
-                    // (of this chunk, or of the last one before it); the first edge pixel outside it ends the line.
-                    if (nz_m) {
-                        const int G = c.line_gap + 1;
-                        uint64_t reach;
-                        if (G <= 0) {
-                            reach = 0;
-                        } else if (G >= 64) {
-                            reach = ~(nz_m ^ (nz_m - 1));            // everything above the lowest edge pixel
-                        } else {
-                            reach = nz_m << 1;                       // distances 1 .. span
-                            int span = 1;
-                            while (span * 2 <= G) { reach |= reach << span; span *= 2; }
-                            if (span < G) reach |= reach << (G - span);
-                        }
-                        const int from_last = G - (base - last_t);   // steps of this chunk still within reach of last_t, minus 1
-                        if (from_last >= 63) reach = ~0ull;
-                        else if (from_last >= 0) reach |= (2ull << from_last) - 1;
-                        const uint64_t fail = nz_m & ~reach;
-                        if (fail) {
-                            done = true;
-                            nz_m &= (fail & (0 - fail)) - 1;         // the edge pixels before the first failure
-                        }
-                        if (nz_m) last_t = base + 63 - __builtin_clzll(nz_m);
+                    for (int q = 0; q < NG; q++) {
+                        nzm[k][g0 + q] = nz[k][q];
+                        wword0[k][g0 + q] = ww[k][q];
+                        if (going[k]) scan(k, (g0 + q) * 64, nz[k][q], inbm[k][q]);
                     }
-                    if (first_oob < 64 || base + 63 - last_t > c.line_gap) done = true;
-                }
-                end_t[k] = last_t;
-                going[k] = !done;
             }
+        }
+        for (int sbase = NC * 64; going[0] || going[1]; sbase += NG * 64) {
+            uint64_t nz[2][NG], inbm[2][NG];
+            uint32_t ww[2][NG];
+            fetch_chunks<LDS_STATE, NG>(c, wk, lane, sbase, going, nz, inbm, ww);
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int q = 0; q < NG; q++)
+                    if (going[k]) scan(k, sbase + q * 64, nz[k][q], inbm[k][q]);
         }
     }
     int ex0, ey0, ex1, ey1;
@@ -447,7 +460,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
         } else {
             const bool want[2] = {sbase <= end_t[0], sbase <= end_t[1]};
             uint64_t inbm[2][NC];
-            fetch(sbase, want, bm, inbm, ww);
+            fetch_chunks<LDS_STATE, NC>(c, wk, lane, sbase, want, bm, inbm, ww);
         }
         uint64_t any = 0;
 #pragma unroll
