@@ -569,9 +569,7 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
 // ---------------------------------------------------------------------------
 struct Slot {
     Work w;
-    hipStream_t st = nullptr;
-    hipStream_t st_lines = nullptr;   // the pipeline's HoughLinesP stream (not owned; null: the kernel runs on st)
-    hipEvent_t ev[10] = {};
+    hipEvent_t ev[12] = {};
     int nframes = 0;
     const uint8_t *input = nullptr;   // device pointer of the frames of the batch in flight
     size_t input_bytes = 0;
@@ -588,66 +586,84 @@ struct lc_pipe {
     int low = 0, high = 0, line_length = 0, line_gap = 0;
     DevBuf<uint64_t> roi_bits;
     bool has_roi = false;
-    // HoughLinesP kernels of all slots run on this one high-priority stream: they want a whole CU's LDS
-    // each, so two of them never overlap anyway, and every further stream costs a hardware queue.
-    hipStream_t st_lines = nullptr;
+    // A pipeline owns three streams, whatever its number of slots; a slot is a set of buffers and events.
+    // (HIP maps streams onto a few hardware queues.  Streams that share one see each other's event waits as
+    // barriers, which at best serialises batches that should overlap and at worst ties two queues into a
+    // knot, so the count stays below the number of hardware queues.)
+    //   st_up     host-to-device copies of submitted frames.
+    //   st_edge   everything before HoughLinesP (front end, hysteresis, compaction, vote) of all slots, in
+    //             submission order.  Those kernels fill the GPU by themselves, so two batches gain nothing
+    //             from running them side by side; what pays is HoughLinesP of batch k beside the edge stage
+    //             of batch k + 1, and serialising the edge stages keeps the slots in that alternating rhythm.
+    //   st_lines  HoughLinesP and the copies of its results.  One workgroup per frame that wants most of a
+    //             CU's LDS: on a high-priority stream the dispatcher places it ahead of the next batch's
+    //             front-end waves instead of behind them.
+    hipStream_t st_up = nullptr, st_edge = nullptr, st_lines = nullptr;
     std::vector<Slot> slots;
 };
 
 namespace {
 
-enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END };
+enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END, EV_ESTART, EV_LSTART };
 
 void enqueue_back(lc_pipe *pp, Slot &s) {
     Work &w = s.w;
     const lc_pipe_params &p = pp->p;
     const int n = s.nframes;
-    (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, s.st);
+    hipStream_t es = pp->st_edge;
+    (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
-                    w.rowplane.p, w.rowcount.p, s.st);
-    (void)hipEventRecord(s.ev[EV_EDGE], s.st);
+                    w.rowplane.p, w.rowcount.p, es);
+    (void)hipEventRecord(s.ev[EV_EDGE], es);
     const bool hough = p.want_accumulator || p.want_segments;
     if (hough) {
-        launch_rowscan(w.g, n, w.rowcount.p, w.rowoff.p, w.npoints.p, s.st);
-        launch_scatter(w.g, n, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, s.st);
+        launch_rowscan(w.g, n, w.rowcount.p, w.rowoff.p, w.npoints.p, es);
+        launch_scatter(w.g, n, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, es);
     }
-    (void)hipEventRecord(s.ev[EV_POINTS], s.st);
+    (void)hipEventRecord(s.ev[EV_POINTS], es);
     if (p.want_accumulator)
-        launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, s.st);
-    (void)hipEventRecord(s.ev[EV_VOTE], s.st);
+        launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, es);
+    (void)hipEventRecord(s.ev[EV_VOTE], es);
+    hipStream_t ls = es;   // the stream the batch finishes on
     if (p.want_segments) {
-        // One workgroup per frame that wants a whole CU's LDS: on its own high-priority stream the
-        // dispatcher places it ahead of the next batch's front-end waves instead of behind them.
-        hipStream_t ls = s.st_lines ? s.st_lines : s.st;
-        if (s.st_lines) (void)hipStreamWaitEvent(ls, s.ev[EV_VOTE], 0);
+        ls = pp->st_lines;
+        if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[EV_VOTE], 0);
+        (void)hipEventRecord(s.ev[EV_LSTART], ls);
         (void)hipMemsetAsync(w.status.p, 0, sizeof(int), ls);
         launch_ppht(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
                     p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p, w.fallback.p,
                     w.rng_out.p, RNG_TABLE, ls);
         (void)hipEventRecord(s.ev[EV_LINES], ls);
-        if (s.st_lines) (void)hipStreamWaitEvent(s.st, s.ev[EV_LINES], 0);
+        (void)hipMemcpyAsync(s.h_segcount, w.segcount.p, sizeof(int) * n, hipMemcpyDeviceToHost, ls);
+        (void)hipMemcpyAsync(s.h_seg, w.seg.p, sizeof(int32_t) * 4 * (size_t)n * w.seg_cap, hipMemcpyDeviceToHost, ls);
+        (void)hipMemcpyAsync(s.h_status, w.status.p, sizeof(int), hipMemcpyDeviceToHost, ls);
     } else {
-        (void)hipEventRecord(s.ev[EV_LINES], s.st);
+        (void)hipEventRecord(s.ev[EV_LSTART], ls);
+        (void)hipEventRecord(s.ev[EV_LINES], ls);
     }
-    if (p.want_segments) {
-        (void)hipMemcpyAsync(s.h_segcount, w.segcount.p, sizeof(int) * n, hipMemcpyDeviceToHost, s.st);
-        (void)hipMemcpyAsync(s.h_seg, w.seg.p, sizeof(int32_t) * 4 * (size_t)n * w.seg_cap, hipMemcpyDeviceToHost, s.st);
-        (void)hipMemcpyAsync(s.h_status, w.status.p, sizeof(int), hipMemcpyDeviceToHost, s.st);
-    }
-    (void)hipMemcpyAsync(s.h_rounds, w.rounds.p, sizeof(int) * n, hipMemcpyDeviceToHost, s.st);
-    (void)hipEventRecord(s.ev[EV_END], s.st);
+    (void)hipMemcpyAsync(s.h_rounds, w.rounds.p, sizeof(int) * n, hipMemcpyDeviceToHost, ls);
+    (void)hipEventRecord(s.ev[EV_END], ls);
 }
 
-int enqueue_all(lc_pipe *pp, Slot &s) {
+// from_host: the frames were just queued for copy on st_up (EV_START is recorded there)
+int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     Work &w = s.w;
     const lc_pipe_params &p = pp->p;
     const int n = s.nframes;
-    HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], s.st));
+    hipStream_t es = pp->st_edge;
+    if (from_host) {
+        HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], pp->st_up));
+        HIP_TRY(hipStreamWaitEvent(es, s.ev[EV_UPLOADED], 0));
+    } else {
+        HIP_TRY(hipEventRecord(s.ev[EV_START], es));
+        HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], es));
+    }
+    HIP_TRY(hipEventRecord(s.ev[EV_ESTART], es));
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
-                 w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, s.st);
-    HIP_TRY(hipEventRecord(s.ev[EV_FRONT], s.st));
-    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.rounds.p, s.st);
-    HIP_TRY(hipEventRecord(s.ev[EV_HYST], s.st));
+                 w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es);
+    HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
+    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.rounds.p, es);
+    HIP_TRY(hipEventRecord(s.ev[EV_HYST], es));
     enqueue_back(pp, s);
     HIP_TRY(hipGetLastError());
     s.busy = true;
@@ -719,18 +735,21 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         pp->has_roi = true;
     }
 
-    const char *pr = getenv("LANECV_LINES_PRIORITY");
-    if (p.want_segments && !(pr && pr[0] == '0')) {
-        int lo_pri = 0, hi_pri = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
-        hipError_t e = hipStreamCreateWithPriority(&pp->st_lines, hipStreamNonBlocking, (pr && pr[0] == '2') ? lo_pri : hi_pri);
-        if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "hipStreamCreateWithPriority failed: %s", hipGetErrorString(e)); }
+    {
+        hipError_t e = hipStreamCreateWithFlags(&pp->st_up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp->st_edge, hipStreamNonBlocking);
+        const char *pr = getenv("LANECV_LINES_PRIORITY");   // diagnostics: 0 keeps HoughLinesP on the edge stream
+        if (e == hipSuccess && p.want_segments && !(pr && pr[0] == '0')) {
+            int lo_pri = 0, hi_pri = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+            e = hipStreamCreateWithPriority(&pp->st_lines, hipStreamNonBlocking, hi_pri);
+        }
+        if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+        if (!pp->st_lines) pp->st_lines = pp->st_edge;
     }
     pp->slots.resize(p.nslots);
     for (Slot &s : pp->slots) {
-        hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
-        if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
-        s.st_lines = pp->st_lines;
+        hipError_t e;
         for (auto &ev : s.ev) {
             e = hipEventCreate(&ev);
             if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
@@ -740,7 +759,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             // point list capacity per frame: an eighth of the pixels (a Canny map inside an ROI stays far below)
             int cap = std::max(1024, (int)std::min<size_t>((size_t)p.width * p.height, (size_t)p.width * p.height / 8 + 1024));
             if ((rc = s.w.init_points(cap))) { lc_pipe_destroy(pp); return rc; }
-            if ((rc = s.w.init_hough(p.rho, p.theta, std::max(p.seg_capacity, 1), p.want_accumulator != 0, p.want_segments != 0, s.st))) {
+            if ((rc = s.w.init_hough(p.rho, p.theta, std::max(p.seg_capacity, 1), p.want_accumulator != 0, p.want_segments != 0, pp->st_edge))) {
                 lc_pipe_destroy(pp);
                 return rc;
             }
@@ -764,15 +783,15 @@ int lc_pipe_destroy(lc_pipe *pipe) {
     if (!pipe) return LC_OK;
     (void)hipSetDevice(pipe->ctx->device);
     for (Slot &s : pipe->slots) {
-        if (s.st) { (void)hipStreamSynchronize(s.st); }
         for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
-        if (s.st) (void)hipStreamDestroy(s.st);
         if (s.h_rounds) (void)hipHostFree(s.h_rounds);
         if (s.h_status) (void)hipHostFree(s.h_status);
         if (s.h_segcount) (void)hipHostFree(s.h_segcount);
         if (s.h_seg) (void)hipHostFree(s.h_seg);
     }
-    if (pipe->st_lines) { (void)hipStreamSynchronize(pipe->st_lines); (void)hipStreamDestroy(pipe->st_lines); }
+    if (pipe->st_lines && pipe->st_lines != pipe->st_edge) { (void)hipStreamSynchronize(pipe->st_lines); (void)hipStreamDestroy(pipe->st_lines); }
+    if (pipe->st_edge) { (void)hipStreamSynchronize(pipe->st_edge); (void)hipStreamDestroy(pipe->st_edge); }
+    if (pipe->st_up) { (void)hipStreamSynchronize(pipe->st_up); (void)hipStreamDestroy(pipe->st_up); }
     delete pipe;
     return LC_OK;
 }
@@ -786,9 +805,9 @@ int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nf
     s->nframes = nframes;
     s->input_bytes = (size_t)nframes * 3 * s->w.npix;
     s->input = s->w.bgr.p;
-    HIP_TRY(hipEventRecord(s->ev[EV_START], s->st));
-    HIP_TRY(hipMemcpyAsync(s->w.bgr.p, host_bgr, s->input_bytes, hipMemcpyHostToDevice, s->st));
-    return enqueue_all(pipe, *s);
+    HIP_TRY(hipEventRecord(s->ev[EV_START], pipe->st_up));
+    HIP_TRY(hipMemcpyAsync(s->w.bgr.p, host_bgr, s->input_bytes, hipMemcpyHostToDevice, pipe->st_up));
+    return enqueue_all(pipe, *s, true);
 }
 
 int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nframes) {
@@ -801,8 +820,7 @@ int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nfra
     s->nframes = nframes;
     s->input_bytes = (size_t)nframes * 3 * s->w.npix;
     s->input = (const uint8_t *)dev_bgr;
-    HIP_TRY(hipEventRecord(s->ev[EV_START], s->st));
-    return enqueue_all(pipe, *s);
+    return enqueue_all(pipe, *s, false);
 }
 
 int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count) {
@@ -810,7 +828,7 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     int rc;
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
-    HIP_TRY(hipStreamSynchronize(s->st));
+    HIP_TRY(hipEventSynchronize(s->ev[EV_END]));
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
     if (p.want_segments) {
@@ -857,12 +875,12 @@ int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms) {
     int a, b;
     switch (stage) {
         case LC_STAGE_UPLOAD: a = EV_START; b = EV_UPLOADED; break;
-        case LC_STAGE_EDGE: a = EV_UPLOADED; b = EV_EDGE; break;
+        case LC_STAGE_EDGE: a = EV_ESTART; b = EV_EDGE; break;
         case LC_STAGE_POINTS: a = EV_EDGE; b = EV_POINTS; break;
         case LC_STAGE_VOTE: a = EV_POINTS; b = EV_VOTE; break;
-        case LC_STAGE_LINES: a = EV_VOTE; b = EV_LINES; break;
+        case LC_STAGE_LINES: a = EV_LSTART; b = EV_LINES; break;
         case LC_STAGE_TOTAL: a = EV_START; b = EV_END; break;
-        case LC_STAGE_FRONT: a = EV_UPLOADED; b = EV_FRONT; break;
+        case LC_STAGE_FRONT: a = EV_ESTART; b = EV_FRONT; break;
         case LC_STAGE_HYST: a = EV_FRONT; b = EV_HYST; break;
         case LC_STAGE_FINAL: a = EV_HYST; b = EV_EDGE; break;
         default: return fail(LC_EINVAL, "unknown stage %d", stage);
@@ -889,8 +907,8 @@ int lc_pipe_upload(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "upload: bad frames argument");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
-    HIP_TRY(hipMemcpyAsync(s->w.bgr.p, host_bgr, (size_t)nframes * 3 * s->w.npix, hipMemcpyHostToDevice, s->st));
-    HIP_TRY(hipStreamSynchronize(s->st));
+    HIP_TRY(hipMemcpyAsync(s->w.bgr.p, host_bgr, (size_t)nframes * 3 * s->w.npix, hipMemcpyHostToDevice, pipe->st_up));
+    HIP_TRY(hipStreamSynchronize(pipe->st_up));
     return LC_OK;
 }
 
