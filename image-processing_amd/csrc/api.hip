@@ -589,7 +589,8 @@ struct lc_pipe {
     // A pipeline owns three streams, whatever its number of slots; a slot is a set of buffers and events.
     // (HIP maps streams onto a few hardware queues.  Streams that share one see each other's event waits as
     // barriers, which at best serialises batches that should overlap and at worst ties two queues into a
-    // knot, so the count stays below the number of hardware queues.)
+    // knot, so the count stays below the number of hardware queues.  The waits between them also run one way
+    // only -- st_up -> st_edge -> st_lines: pairs of streams that waited on each other in turn have hung.)
     //   st_up     host-to-device copies of submitted frames.
     //   st_edge   everything before HoughLinesP (front end, hysteresis, compaction, vote) of all slots, in
     //             submission order.  Those kernels fill the GPU by themselves, so two batches gain nothing
