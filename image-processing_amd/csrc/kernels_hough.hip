@@ -149,6 +149,7 @@ struct Walk {
 #ifdef LC_STAMPS
 __device__ long long g_stamps[8];   // diagnostic build only: cycle sums of frame 0
 __device__ unsigned long long g_dbg[4];
+__device__ int g_simd[8];
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
 #ifndef PPHT_Q
@@ -165,6 +166,7 @@ struct Ppht {
     int32_t *acc;              // global accumulator (general path)
     int32_t *seg;
     // fast path: the frame's edge bits live in LDS, only the word span of every row that has points
+    const AngleEntry *ltab;    // LDS copy of tab (walk steps of every angle)
     uint64_t *lmask;           // the spans, back to back
     const uint32_t *rowtab;    // per row ymin + r: first LDS word (bits 0-15), first image word (16-23), words (24-31)
     int ymin, nrows;
@@ -358,7 +360,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
                                             const VoteLane &vl, LineOut &lo) {
     constexpr int NC = LINE_NC;
     bool inflight = false;   // a vote-removal job of this line is with the helpers
-    const AngleEntry e = c.tab[max_n];
+    const AngleEntry e = LDS_STATE ? c.ltab[max_n] : c.tab[max_n];
     Walk wk;
     wk.xflag = e.xflag;
     if (e.xflag) { wk.x0 = j; wk.y0 = (i << 16) + 32768; wk.dx = e.dmaj; wk.dy = e.dmin; }
@@ -475,6 +477,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
                 if (k == 1 && base == 0) m &= ~1ull;                    // t = 0 belongs to direction 0
                 bm[k][q] = m;
                 any |= m;
+                if (m == 0) continue;
                 if ((m >> lane) & 1) {
                     int j1, i1;
                     wk.at(base + lane, k ? -1 : 1, j1, i1);
@@ -522,7 +525,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
 #ifdef LC_STAMPS
     long long ts3 = STAMP();
 #endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!LDS_STATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the cleared bits are in L2 before the next pick reads them
 #ifdef LC_STAMPS
     if (blockIdx.x == 0 && lane == 0) {
         g_dbg[0] += ts1 - ts0; g_dbg[1] += ts2 - ts1; g_dbg[2] += ts3 - ts2; g_dbg[3] += STAMP() - ts3;
@@ -618,10 +621,14 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     __shared__ int s_xmin, s_xmax, s_maskwords, s_accbins;
     __shared__ int s_part[PPHT_THREADS];
     __shared__ uint32_t a_base[64], a_rfix[64], a_wid[64];
+    __shared__ AngleEntry s_tab[64];
     // this kernel is a few latency-bound wavefronts per CU: let them issue ahead of the streaming
     // kernels of other batches that share the SIMDs
     __builtin_amdgcn_s_setprio(3);
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef LC_STAMPS
+    if (f == 0 && lane == 0) g_simd[wave] = __builtin_amdgcn_s_getreg(2308);
+#endif
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
     const int n = npoints[f];
     if (n > nz_cap) {
@@ -658,22 +665,32 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
         s_xmin = INT_MAX; s_xmax = 0;
     }
     for (int r = tid; r < nrows; r += PPHT_THREADS) rowtab[r] = 0;
+    if (tid < numangle) s_tab[tid] = tab[tid];
     __syncthreads();
     {
         int xmin = INT_MAX, xmax = 0;
         for (int i = tid; i < n; i += PPHT_THREADS) {
             const uint32_t pt = nz[i];
             lnz[i] = pt;
-            const int x = (int)(pt & 0xFFFF), y = (int)(pt >> 16);
+            const int x = (int)(pt & 0xFFFF);
             xmin = min(xmin, x); xmax = max(xmax, x);
-            // first / last point of its row: they bound the row's span (bit 0 marks a row that has points)
-            const bool first = i == 0 || (int)(nz[i - 1] >> 16) != y;
-            const bool last = i == n - 1 || (int)(nz[i + 1] >> 16) != y;
-            if (first) atomicOr(&rowtab[y - ymin], 1u | ((uint32_t)(x >> 6) << 16));
-            if (last) atomicOr(&rowtab[y - ymin], (uint32_t)(x >> 6) << 24);
         }
-        atomicMin(&s_xmin, xmin);
-        atomicMax(&s_xmax, xmax);
+        // wave-level reduction first: one LDS atomic per wave
+        for (int d = 32; d >= 1; d >>= 1) {
+            xmin = min(xmin, __shfl_xor(xmin, d));
+            xmax = max(xmax, __shfl_xor(xmax, d));
+        }
+        if (lane == 0) { atomicMin(&s_xmin, xmin); atomicMax(&s_xmax, xmax); }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += PPHT_THREADS) {
+        // first / last point of its row: they bound the row's span (bit 0 marks a row that has points)
+        const uint32_t pt = lnz[i];
+        const int x = (int)(pt & 0xFFFF), y = (int)(pt >> 16);
+        const bool first = i == 0 || (int)(lnz[i - 1] >> 16) != y;
+        const bool last = i == n - 1 || (int)(lnz[i + 1] >> 16) != y;
+        if (first) atomicOr(&rowtab[y - ymin], 1u | ((uint32_t)(x >> 6) << 16));
+        if (last) atomicOr(&rowtab[y - ymin], (uint32_t)(x >> 6) << 24);
     }
     __syncthreads();
     {   // exclusive scan of the span lengths over the rows -> first LDS word of every row
@@ -740,6 +757,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     c.lacc = reinterpret_cast<int16_t *>(lds32 + acc_off);
     c.lmask = reinterpret_cast<uint64_t *>(lds32 + mask_off);
     c.rowtab = rowtab; c.ymin = ymin; c.nrows = nrows;
+    c.ltab = s_tab;
     for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[acc_off + i] = (uint32_t)LDS_BIAS * 0x10001u;
     for (int r = wave; r < nrows; r += PPHT_THREADS / 64) {
         const uint32_t e = rowtab[r];
@@ -766,22 +784,41 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
 #ifdef LC_STAMPS
         long long tp0 = STAMP();
 #endif
-        // rng_out[k] is the k-th output of cv::RNG(2^64 - 1) (fixed seed, so a host-made table);
-        // 64 lanes reduce 64 picks modulo their counts at once, the swap-removes then run in order
+        // rng_out[k] is the k-th output of cv::RNG(2^64 - 1) (fixed seed, so a host-made table).
+        // 64 picks at a time: lane t holds pick t's index and the two array elements its swap-remove
+        // reads, as they were before the batch.  The swaps then run in order on those registers -- a
+        // write of an earlier pick is forwarded to the later lanes that read the same slot -- and the
+        // array is updated with two vector stores, instead of 64 dependent LDS round trips.
+        uint32_t rnd = lane < n ? rng_out[lane] : 0u;         // the random numbers are fetched a batch ahead
         for (int k0 = 0; k0 < n; k0 += 64) {
             const int k = k0 + lane;
-            uint32_t idxv = 0;
-            if (k < n) idxv = rng_out[k] % (uint32_t)(n - k);
             const int m = min(64, n - k0);
-            for (int t = 0; t < m; t++) {
-                const uint32_t idx = __shfl(idxv, t);
-                const int cnt = n - (k0 + t);
-                if (lane == 0) {
-                    const uint32_t pt = lnz[idx], last = lnz[cnt - 1];
-                    lnz[idx] = last;
-                    lnz[cnt - 1] = pt;
-                }
+            const bool on = lane < m;
+            const uint32_t rcur = rnd;
+            if (k + 64 < n) rnd = rng_out[k + 64];
+            uint32_t idx = 0xFFFFFFFFu, cpos = 0xFFFFFFFEu;   // slot picked / last slot of the shrinking array
+            uint32_t acur = 0, bcur = 0;
+            if (on) {
+                idx = rcur % (uint32_t)(n - k);
+                cpos = (uint32_t)(n - k - 1);
+                acur = lnz[idx];
+                bcur = lnz[cpos];
             }
+            uint64_t overwritten = 0;   // picks whose slot a later pick of the batch writes again
+            for (int t = 0; t < m; t++) {
+                const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)idx, t);
+                const uint64_t later = ~((2ull << t) - 1);
+                // later picks that read the slot this pick writes: as their own pick / as their last element
+                const uint64_t same_a = __ballot(idx == it) & later, same_b = __ballot(cpos == it) & later;
+                if ((same_a | same_b) == 0) continue;       // the common case: nobody to forward to
+                const uint32_t lastv = (uint32_t)__builtin_amdgcn_readlane((int)bcur, t);
+                acur = ((same_a >> lane) & 1) ? lastv : acur;     // the slot now holds what was the last element
+                bcur = ((same_b >> lane) & 1) ? lastv : bcur;
+                if (same_a) overwritten |= 1ull << t;
+            }
+            // lane t: acur = the point pick t removes, bcur = the last element that takes its slot
+            if (on && !((overwritten >> lane) & 1)) lnz[idx] = bcur;
+            if (on) lnz[cpos] = acur;             // after the slot writes: a later pick's own slot wins
             if (lane == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 *(volatile int *)&progress = k0 + m;
@@ -975,6 +1012,7 @@ void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoint
 #ifdef LC_STAMPS
 extern "C" int lc_debug_stamps(long long *out) {
     (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_dbg), sizeof(long long) * 4);
+    (void)hipMemcpyFromSymbol(out + 12, HIP_SYMBOL(g_simd), sizeof(int) * 8);
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 8);
 }
 #endif
