@@ -3,7 +3,7 @@
 A `Recipe` names one of the reference's per-frame call sequences; `LanePipeline`
 configures the HIP pipeline for it once (ROI mask rasterised once per shape instead
 of per frame, as the scripts do at `Simple Lane Detection with OpenCV_2(images).py:14-23`)
-and then processes batches of independent frames on `nslots` HIP streams:
+and then processes batches of independent frames in `nslots` slots (buffer sets) that overlap on the GPU:
 
     pipe = LanePipeline(1920, 1080, Recipe.north_star(1920, 1080), max_batch=256, nslots=3)
     pipe.submit(0, frames)            # (n, h, w, 3) uint8, pinned or pageable host memory

@@ -1,0 +1,21 @@
+import sys, os, time, dataclasses
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "image-processing_amd")]
+import numpy as np
+from lanecv import synth, _abi
+from lanecv.pipeline import LanePipeline, Recipe
+batch = 256
+import multiprocessing as mp
+def gen(t): return synth.synth_road(1920, 1080, 100, t)
+with mp.get_context("fork").Pool(16) as pool:
+    frames = np.stack(pool.map(gen, range(batch), chunksize=4))
+for canny in [(100, 200), (100000, 200000)]:
+    rec = dataclasses.replace(Recipe.north_star(1920, 1080), canny=canny, segments=False, accumulator=False)
+    pipe = LanePipeline(1920, 1080, rec, max_batch=batch, nslots=1, seg_capacity=128, device=0)
+    ptr = pipe.upload(0, frames)
+    ts = []
+    for i in range(6):
+        pipe.submit_device(0, ptr, batch); pipe.wait(0)
+        ts.append([pipe.stage_ms(0, s) for s in (_abi.STAGE_FRONT, _abi.STAGE_HYST, _abi.STAGE_FINAL)])
+    print(canny, np.median(np.array(ts), axis=0).round(4), flush=True)
+    pipe.close()

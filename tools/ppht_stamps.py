@@ -1,8 +1,8 @@
 import sys, os, ctypes as C
-sys.path.insert(0, 'image-processing_amd'); sys.path.insert(0, '.')
+sys.path.insert(0, 'image-processing_amd'); sys.path.insert(0, '.')  # run from the repository root
 import numpy as np
 from lanecv import _abi
-_abi._SO = os.path.abspath('scratch/liblanecv_stamps.so')
+_abi._SO = os.path.abspath('tools/liblanecv_stamps.so')
 from lanecv import synth
 from lanecv.pipeline import LanePipeline, Recipe
 w,h=1920,1080
@@ -15,5 +15,5 @@ for it in range(1):
 out=(C.c_longlong*48)()
 print('rc', _abi.lib().lc_debug_stamps(out))
 names=['producer_cycles','consumer_cycles','wait','vote','line','n_alive','n_line','n']
-print({k:int(v) for k,v in zip(names,out)}); print('dbg', list(out)[8:12])
+print({k:int(v) for k,v in zip(names,out)}); print('dbg', list(out)[8:12]); import struct; print('simd', struct.unpack('8i', struct.pack('4q', *list(out)[12:16])))
 print('lines ms', pipe.stage_ms(0,_abi.STAGE_LINES))
