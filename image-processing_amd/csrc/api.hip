@@ -592,7 +592,7 @@ struct lc_pipe {
     // knot, so the count stays below the number of hardware queues.  The waits between them also run one way
     // only -- st_up -> st_edge -> st_lines: pairs of streams that waited on each other in turn have hung.)
     //   st_up     host-to-device copies of submitted frames.
-    //   st_edge   everything before HoughLinesP (front end, hysteresis, compaction, vote) of all slots, in
+    //   st_edge   everything before HoughLinesP (front end, hysteresis, compaction) of all slots, in
     //             submission order.  Those kernels fill the GPU by themselves, so two batches gain nothing
     //             from running them side by side; what pays is HoughLinesP of batch k beside the edge stage
     //             of batch k + 1, and serialising the edge stages keeps the slots in that alternating rhythm.
@@ -622,14 +622,23 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
         launch_scatter(w.g, n, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, es);
     }
     (void)hipEventRecord(s.ev[EV_POINTS], es);
-    if (p.want_accumulator)
+    // The full-vote accumulator depends only on the point list.  With segments wanted it runs on the
+    // HoughLinesP stream, ahead of that kernel (whose fallback path permutes the point list): it uses LDS,
+    // which HoughLinesP of the previous batch nearly fills, so on the edge stream it would hold up the next
+    // batch's front end.  Its stage time is then EV_LSTART -> EV_VOTE, and HoughLinesP's EV_VOTE -> EV_LINES.
+    const bool vote_late = p.want_accumulator && p.want_segments && pp->st_lines != es;
+    if (p.want_accumulator && !vote_late)
         launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, es);
-    (void)hipEventRecord(s.ev[EV_VOTE], es);
+    if (!vote_late) (void)hipEventRecord(s.ev[EV_VOTE], es);
     hipStream_t ls = es;   // the stream the batch finishes on
     if (p.want_segments) {
         ls = pp->st_lines;
-        if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[EV_VOTE], 0);
+        if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[EV_POINTS], 0);
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
+        if (vote_late) {
+            launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, ls);
+            (void)hipEventRecord(s.ev[EV_VOTE], ls);
+        }
         (void)hipMemsetAsync(w.status.p, 0, sizeof(int), ls);
         launch_ppht(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
                     p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p, w.fallback.p,
@@ -878,8 +887,14 @@ int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms) {
         case LC_STAGE_UPLOAD: a = EV_START; b = EV_UPLOADED; break;
         case LC_STAGE_EDGE: a = EV_ESTART; b = EV_EDGE; break;
         case LC_STAGE_POINTS: a = EV_EDGE; b = EV_POINTS; break;
-        case LC_STAGE_VOTE: a = EV_POINTS; b = EV_VOTE; break;
-        case LC_STAGE_LINES: a = EV_LSTART; b = EV_LINES; break;
+        case LC_STAGE_VOTE:   // on the HoughLinesP stream, ahead of that kernel, when both are wanted
+            a = (pipe->p.want_accumulator && pipe->p.want_segments && pipe->st_lines != pipe->st_edge) ? EV_LSTART : EV_POINTS;
+            b = EV_VOTE;
+            break;
+        case LC_STAGE_LINES:
+            a = (pipe->p.want_accumulator && pipe->p.want_segments && pipe->st_lines != pipe->st_edge) ? EV_VOTE : EV_LSTART;
+            b = EV_LINES;
+            break;
         case LC_STAGE_TOTAL: a = EV_START; b = EV_END; break;
         case LC_STAGE_FRONT: a = EV_ESTART; b = EV_FRONT; break;
         case LC_STAGE_HYST: a = EV_FRONT; b = EV_HYST; break;
