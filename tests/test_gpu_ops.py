@@ -196,6 +196,46 @@ def test_hough_lines_p_dense_and_empty(cv2, oracle):
     assert got.shape == ref.shape and (got == ref).all()
 
 
+def _same_lines(cv2, oracle, e, rho, theta, thr, minlen, gap):
+    got = cv2.HoughLinesP(e, rho, theta, thr, minLineLength=minlen, maxLineGap=gap)
+    ref = oracle.hough_lines_p(e, rho, theta, thr, minlen, gap)
+    assert (got is None) == (ref is None), (e.shape, thr, minlen, gap)
+    if ref is not None:
+        assert got.shape == ref.shape and (got == ref).all(), (e.shape, thr, minlen, gap)
+    return 0 if ref is None else len(ref)
+
+
+def test_hough_lines_p_lds_path_edges(cv2, oracle):
+    """Shapes that stress the all-in-LDS HoughLinesP kernel (at most 64 angles): degenerate point sets, every point
+    starting a line, zero gap, lines longer than one fetch stretch, wide row spans, and frames too big for LDS."""
+    th = np.pi / 60
+    one = np.zeros((40, 70), np.uint8); one[17, 33] = 255
+    _same_lines(cv2, oracle, one, 6, th, 1, 0, 0)
+    row = np.zeros((40, 300), np.uint8); row[21, 3:290:2] = 255                 # all points in one row, gaps of 1
+    assert _same_lines(cv2, oracle, row, 6, th, 20, 10, 1) > 0
+    _same_lines(cv2, oracle, row, 6, th, 20, 10, 0)                             # gap 0: every hole ends the line
+    far = np.zeros((400, 90), np.uint8); far[2, 5:80] = 255; far[397, 10:85] = 255   # two rows far apart
+    assert _same_lines(cv2, oracle, far, 3, th, 30, 20, 3) == 2
+    rng = np.random.default_rng(11)
+    for k in range(3):                                                          # threshold 1: every alive point walks a line
+        e = (rng.random((48, 64)) < 0.15).astype(np.uint8) * 255
+        _same_lines(cv2, oracle, e, 2, th, 1, 3 * k, k)
+    big = np.zeros((720, 1280), np.uint8)                                       # lines of 600+ steps, with holes
+    for x in range(40, 1240):
+        if x % 37 > 2:
+            big[int(30 + 0.5 * x), x] = 255
+            big[int(700 - 0.52 * x), x] = 255
+    big[100:700, 640] = 255
+    assert _same_lines(cv2, oracle, big, 6, th, 100, 40, 25) >= 3
+    wide = np.zeros((64, 4096), np.uint8); wide[30, 10:4090] = 255; wide[10:50, 2048] = 255
+    wide[(np.arange(4000) // 100 + 5) % 64, np.arange(4000) + 40] = 255
+    _same_lines(cv2, oracle, wide, 6, th, 80, 40, 10)
+    dense = (rng.random((360, 640)) < 0.03).astype(np.uint8) * 255              # ~6900 points: fits
+    _same_lines(cv2, oracle, dense, 6, th, 60, 30, 4)
+    denser = (rng.random((360, 640)) < 0.09).astype(np.uint8) * 255             # ~20700 points: general kernel
+    _same_lines(cv2, oracle, denser, 6, th, 150, 30, 4)
+
+
 def test_errors(cv2):
     g = np.zeros((10, 10), np.uint8)
     with pytest.raises(Exception):
