@@ -622,9 +622,6 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     __shared__ int s_part[PPHT_THREADS];
     __shared__ uint32_t a_base[64], a_rfix[64], a_wid[64];
     __shared__ AngleEntry s_tab[64];
-    // this kernel is a few latency-bound wavefronts per CU: let them issue ahead of the streaming
-    // kernels of other batches that share the SIMDs
-    __builtin_amdgcn_s_setprio(3);
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef LC_STAMPS
     if (f == 0 && lane == 0) g_simd[wave] = __builtin_amdgcn_s_getreg(2308);
