@@ -75,25 +75,36 @@ __global__ __launch_bounds__(256) void k_scatter(Geo g, int nframes, const uint6
     }
 }
 
-// full-vote accumulator: block (group, frame) owns `apg` angle rows in LDS
+// full-vote accumulator: block (group, frame) owns `apg` angle rows in LDS.
+// The points come sorted by row and column, so neighbouring lanes of a wavefront mostly hit the same
+// bin of an angle (rho moves by less than one bin per pixel) and plain per-lane atomics would serialise
+// on that address.  Each run of equal bins is therefore added once, by its first lane, with the run's
+// length: a DPP shift finds the run starts, a ballot and a count of trailing zeros their lengths.
 __global__ __launch_bounds__(256) void k_vote(const uint32_t *__restrict__ nz, int nz_cap, const int *__restrict__ npoints,
                                                const AngleEntry *__restrict__ tab, int numangle, int numrho, int apg,
                                                int32_t *__restrict__ acc) {
     extern __shared__ int lacc[];
     const int f = blockIdx.y, a0 = blockIdx.x * apg;
     const int na = min(apg, numangle - a0);
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
     for (int i = tid; i < na * numrho; i += nt) lacc[i] = 0;
     __syncthreads();
     const int n = min(npoints[f], nz_cap);
     const int half = (numrho - 1) / 2;
     const uint32_t *pts = nz + (size_t)f * nz_cap;
-    for (int p = tid; p < n; p += nt) {
-        uint32_t pt = pts[p];
-        int x = pt & 0xFFFF, y = pt >> 16;
+    for (int p0 = tid - lane; p0 < n; p0 += nt) {       // wave-uniform trip count: 64 consecutive points per wavefront
+        const int p = p0 + lane;
+        const bool valid = p < n;
+        const uint32_t pt = valid ? pts[p] : 0u;
+        const int x = pt & 0xFFFF, y = pt >> 16;
         for (int a = 0; a < na; a++) {
-            int r = rho_bin(x, y, tab[a0 + a].c, tab[a0 + a].s, half);
-            if ((unsigned)r < (unsigned)numrho) atomicAdd(&lacc[a * numrho + r], 1);
+            const int r = rho_bin(x, y, tab[a0 + a].c, tab[a0 + a].s, half);
+            const int key = (valid && (unsigned)r < (unsigned)numrho) ? r : -1;
+            const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138, 0xF, 0xF, false);   // lane - 1's key; lane 0 gets -2
+            const uint64_t starts = __ballot(key != prev);
+            const uint64_t above = lane == 63 ? 0ull : (starts >> (lane + 1));
+            const int len = above ? __builtin_ctzll(above) + 1 : 64 - lane;                 // lanes to the next run start
+            if (key != prev && key >= 0) atomicAdd(&lacc[a * numrho + key], len);
         }
     }
     __syncthreads();
