@@ -523,7 +523,7 @@ int lc_hough_accum(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride,
     if ((long long)acc_capacity < (long long)na * nr) return fail(LC_ECAP, "accumulator needs %d x %d int32", na, nr);
     if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
     if ((rc = points_from_bytes(ctx, nullptr))) return rc;
-    launch_vote(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.tab.p, na, nr, wk.acc_full.p, ctx->stream);
+    launch_vote(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.tab.p, na, nr, wk.acc_full.p, nullptr, ctx->stream);
     HIP_TRY(hipMemcpyAsync(acc, wk.acc_full.p, sizeof(int32_t) * (size_t)na * nr, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return LC_OK;
@@ -544,9 +544,12 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
     if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
     if ((rc = points_from_bytes(ctx, nullptr))) return rc;
     HIP_TRY(hipMemsetAsync(wk.status.p, 0, sizeof(int), ctx->stream));
-    launch_ppht(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, wk.acc_ppht.p, threshold,
-                (int)lrint(min_line_length), (int)lrint(max_line_gap), wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p,
-                wk.rng_out.p, RNG_TABLE, ctx->stream);
+    const int line_length = (int)lrint(min_line_length), line_gap = (int)lrint(max_line_gap);
+    const bool fast = launch_ppht_fast(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, threshold, line_length,
+                                       line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, RNG_TABLE,
+                                       nullptr, ctx->stream);
+    launch_ppht_general(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, wk.acc_ppht.p, threshold, line_length,
+                        line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, fast ? wk.fallback.p : nullptr, ctx->stream);
     int host[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&host[0], wk.segcount.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&host[1], wk.status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -605,7 +608,7 @@ struct lc_pipe {
 
 namespace {
 
-enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END, EV_ESTART, EV_LSTART };
+enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END, EV_ESTART, EV_LSTART, EV_VSTART };
 
 void enqueue_back(lc_pipe *pp, Slot &s) {
     Work &w = s.w;
@@ -622,27 +625,32 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
         launch_scatter(w.g, n, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, es);
     }
     (void)hipEventRecord(s.ev[EV_POINTS], es);
-    // The full-vote accumulator depends only on the point list.  With segments wanted it runs on the
-    // HoughLinesP stream, ahead of that kernel (whose fallback path permutes the point list): it uses LDS,
-    // which HoughLinesP of the previous batch nearly fills, so on the edge stream it would hold up the next
-    // batch's front end.  Its stage time is then EV_LSTART -> EV_VOTE, and HoughLinesP's EV_VOTE -> EV_LINES.
-    const bool vote_late = p.want_accumulator && p.want_segments && pp->st_lines != es;
-    if (p.want_accumulator && !vote_late)
-        launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, es);
-    if (!vote_late) (void)hipEventRecord(s.ev[EV_VOTE], es);
+    // The full-vote accumulator depends only on the point list.  With segments wanted, the HoughLinesP kernel
+    // produces it on the side (its helper wavefronts, from the same LDS-resident set-up) and the vote kernel
+    // only runs for the frames that kernel flags; it sits between the two HoughLinesP steps because the
+    // general one permutes the point list.  Stage times: VOTE = that flagged launch, LINES = both steps.
+    const bool vote_fused = p.want_accumulator && p.want_segments;
+    if (p.want_accumulator && !vote_fused)
+        launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, nullptr, es);
+    if (!vote_fused) (void)hipEventRecord(s.ev[EV_VOTE], es);
     hipStream_t ls = es;   // the stream the batch finishes on
     if (p.want_segments) {
         ls = pp->st_lines;
         if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[EV_POINTS], 0);
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
-        if (vote_late) {
-            launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, ls);
+        (void)hipMemsetAsync(w.status.p, 0, sizeof(int), ls);
+        const bool fast = launch_ppht_fast(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
+                                           p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p,
+                                           w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls);
+        if (vote_fused) {
+            (void)hipEventRecord(s.ev[EV_VSTART], ls);
+            launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p,
+                        fast ? w.fallback.p : nullptr, ls);
             (void)hipEventRecord(s.ev[EV_VOTE], ls);
         }
-        (void)hipMemsetAsync(w.status.p, 0, sizeof(int), ls);
-        launch_ppht(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
-                    p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p, w.fallback.p,
-                    w.rng_out.p, RNG_TABLE, ls);
+        launch_ppht_general(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
+                            p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p,
+                            fast ? w.fallback.p : nullptr, ls);
         (void)hipEventRecord(s.ev[EV_LINES], ls);
         (void)hipMemcpyAsync(s.h_segcount, w.segcount.p, sizeof(int) * n, hipMemcpyDeviceToHost, ls);
         (void)hipMemcpyAsync(s.h_seg, w.seg.p, sizeof(int32_t) * 4 * (size_t)n * w.seg_cap, hipMemcpyDeviceToHost, ls);
@@ -887,14 +895,11 @@ int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms) {
         case LC_STAGE_UPLOAD: a = EV_START; b = EV_UPLOADED; break;
         case LC_STAGE_EDGE: a = EV_ESTART; b = EV_EDGE; break;
         case LC_STAGE_POINTS: a = EV_EDGE; b = EV_POINTS; break;
-        case LC_STAGE_VOTE:   // on the HoughLinesP stream, ahead of that kernel, when both are wanted
-            a = (pipe->p.want_accumulator && pipe->p.want_segments && pipe->st_lines != pipe->st_edge) ? EV_LSTART : EV_POINTS;
+        case LC_STAGE_VOTE:   // with segments wanted: only the launch for the frames HoughLinesP flagged
+            a = (pipe->p.want_accumulator && pipe->p.want_segments) ? EV_VSTART : EV_POINTS;
             b = EV_VOTE;
             break;
-        case LC_STAGE_LINES:
-            a = (pipe->p.want_accumulator && pipe->p.want_segments && pipe->st_lines != pipe->st_edge) ? EV_VOTE : EV_LSTART;
-            b = EV_LINES;
-            break;
+        case LC_STAGE_LINES: a = EV_LSTART; b = EV_LINES; break;
         case LC_STAGE_TOTAL: a = EV_START; b = EV_END; break;
         case LC_STAGE_FRONT: a = EV_ESTART; b = EV_FRONT; break;
         case LC_STAGE_HYST: a = EV_FRONT; b = EV_HYST; break;

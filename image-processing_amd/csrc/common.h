@@ -62,13 +62,16 @@ void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowpl
 void launch_rowscan(Geo g, int nframes, const int *rowcount, int *rowoff, int *npoints, hipStream_t st);
 void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, const int *rowcount, const int *rowoff, uint32_t *nz,
                     int nz_cap, hipStream_t st);
-void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints,
-                 const AngleEntry *tab, int numangle, int numrho, int32_t *acc, hipStream_t st);
-void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
-                 const AngleEntry *tab, int numangle, int numrho, int32_t *acc,
-                 int threshold, int line_length, int line_gap,
-                 int32_t *seg, int seg_cap, int *seg_count, int *status, int *fallback,
-                 const uint32_t *rng_out, int rng_len, hipStream_t st);
+void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
+                 int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st);
+bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
+                      const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
+                      int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
+                      int rng_len, int32_t *acc_full, hipStream_t st);
+void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
+                         const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
+                         int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, const int *flags,
+                         hipStream_t st);
 // polygons
 struct PolyEdgeDev { int y0, y1; long long x, dx; };
 struct LineDev { int x0, y0, count, vert, dmaj, dmin, dmajor_len, dminor_len; };

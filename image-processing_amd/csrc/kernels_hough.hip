@@ -82,34 +82,39 @@ __global__ __launch_bounds__(256) void k_scatter(Geo g, int nframes, const uint6
 // length: a DPP shift finds the run starts, a ballot and a count of trailing zeros their lengths.
 __global__ __launch_bounds__(256) void k_vote(const uint32_t *__restrict__ nz, int nz_cap, const int *__restrict__ npoints,
                                                const AngleEntry *__restrict__ tab, int numangle, int numrho, int apg,
-                                               int32_t *__restrict__ acc) {
+                                               int32_t *__restrict__ acc, const int *__restrict__ flags) {
     extern __shared__ int lacc[];
-    const int f = blockIdx.y, a0 = blockIdx.x * apg;
-    const int na = min(apg, numangle - a0);
+    const int f = blockIdx.y;
+    if (flags && !(flags[f] & 2)) return;   // HoughLinesP already produced this frame's accumulator
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
-    for (int i = tid; i < na * numrho; i += nt) lacc[i] = 0;
-    __syncthreads();
     const int n = min(npoints[f], nz_cap);
     const int half = (numrho - 1) / 2;
     const uint32_t *pts = nz + (size_t)f * nz_cap;
-    for (int p0 = tid - lane; p0 < n; p0 += nt) {       // wave-uniform trip count: 64 consecutive points per wavefront
-        const int p = p0 + lane;
-        const bool valid = p < n;
-        const uint32_t pt = valid ? pts[p] : 0u;
-        const int x = pt & 0xFFFF, y = pt >> 16;
-        for (int a = 0; a < na; a++) {
-            const int r = rho_bin(x, y, tab[a0 + a].c, tab[a0 + a].s, half);
-            const int key = (valid && (unsigned)r < (unsigned)numrho) ? r : -1;
-            const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138, 0xF, 0xF, false);   // lane - 1's key; lane 0 gets -2
-            const uint64_t starts = __ballot(key != prev);
-            const uint64_t above = lane == 63 ? 0ull : (starts >> (lane + 1));
-            const int len = above ? __builtin_ctzll(above) + 1 : 64 - lane;                 // lanes to the next run start
-            if (key != prev && key >= 0) atomicAdd(&lacc[a * numrho + key], len);
+    // a block takes the angle groups blockIdx.x, blockIdx.x + gridDim.x, ... (all of them in the flagged launch)
+    for (int a0 = blockIdx.x * apg; a0 < numangle; a0 += gridDim.x * apg) {
+        const int na = min(apg, numangle - a0);
+        __syncthreads();
+        for (int i = tid; i < na * numrho; i += nt) lacc[i] = 0;
+        __syncthreads();
+        for (int p0 = tid - lane; p0 < n; p0 += nt) {       // wave-uniform trip count: 64 consecutive points per wavefront
+            const int p = p0 + lane;
+            const bool valid = p < n;
+            const uint32_t pt = valid ? pts[p] : 0u;
+            const int x = pt & 0xFFFF, y = pt >> 16;
+            for (int a = 0; a < na; a++) {
+                const int r = rho_bin(x, y, tab[a0 + a].c, tab[a0 + a].s, half);
+                const int key = (valid && (unsigned)r < (unsigned)numrho) ? r : -1;
+                const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138, 0xF, 0xF, false);   // lane - 1's key; lane 0 gets -2
+                const uint64_t starts = __ballot(key != prev);
+                const uint64_t above = lane == 63 ? 0ull : (starts >> (lane + 1));
+                const int len = above ? __builtin_ctzll(above) + 1 : 64 - lane;                 // lanes to the next run start
+                if (key != prev && key >= 0) atomicAdd(&lacc[a * numrho + key], len);
+            }
         }
+        __syncthreads();
+        int32_t *out = acc + ((size_t)f * numangle + a0) * numrho;
+        for (int i = tid; i < na * numrho; i += nt) out[i] = lacc[i];
     }
-    __syncthreads();
-    int32_t *out = acc + ((size_t)f * numangle + a0) * numrho;
-    for (int i = tid; i < na * numrho; i += nt) out[i] = lacc[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restric
                                                       int *__restrict__ seg_count, int *__restrict__ status,
                                                       const int *__restrict__ fallback) {
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    if (fallback && !fallback[f]) return;
+    if (fallback && !(fallback[f] & 1)) return;
     uint32_t *nz = nz_all + (size_t)f * nz_cap;
     Ppht c;
     c.W = g.W; c.H = g.H; c.TX = g.TX; c.numangle = numangle; c.numrho = numrho; c.half = (numrho - 1) / 2;
@@ -625,13 +630,16 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
                                                    int threshold, int line_length, int line_gap,
                                                    int32_t *__restrict__ seg_all, int seg_cap, int *__restrict__ seg_count,
                                                    int *__restrict__ status, int *__restrict__ fallback, int lds_points,
-                                                   const uint32_t *__restrict__ rng_out, int lds_bytes) {
+                                                   const uint32_t *__restrict__ rng_out, int lds_bytes,
+                                                   int32_t *__restrict__ acc_full) {
     extern __shared__ __align__(16) uint32_t lds32[];
     __shared__ int progress;
     __shared__ Jobs jobs;
     __shared__ int s_xmin, s_xmax, s_maskwords, s_accbins;
     __shared__ int s_part[PPHT_THREADS];
     __shared__ uint32_t a_base[64], a_rfix[64], a_wid[64];
+    __shared__ int a_rmin[64];
+    __shared__ int vote_done;
     __shared__ AngleEntry s_tab[64];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef LC_STAMPS
@@ -640,15 +648,15 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
     const int n = npoints[f];
     if (n > nz_cap) {
-        if (tid == 0) { seg_count[f] = 0; fallback[f] = 0; atomicOr(status, 1); }
+        if (tid == 0) { seg_count[f] = 0; fallback[f] = 2; atomicOr(status, 1); }
         return;
     }
     if (n == 0) {
-        if (tid == 0) { seg_count[f] = 0; fallback[f] = 0; }
+        if (tid == 0) { seg_count[f] = 0; fallback[f] = 2; }
         return;
     }
     if (n > lds_points || n >= LDS_BIAS) {   // biased 16-bit bins hold counts in (-LDS_BIAS, LDS_BIAS)
-        if (tid == 0) fallback[f] = 1;
+        if (tid == 0) fallback[f] = 3;
         return;
     }
     Ppht c;
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     const int nrows = ymax - ymin + 1;
     uint32_t *rowtab = lds32 + n;
     if (tid == 0) {
-        progress = 0; fallback[f] = 0;
+        progress = 0; vote_done = 0;
         jobs.seq = 0; jobs.done = 0;
         s_xmin = INT_MAX; s_xmax = 0;
     }
@@ -749,6 +757,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
         a_base[lane] = lane < numangle ? (uint32_t)(incl - nb) : 0u;
         a_wid[lane] = lane < numangle ? (uint32_t)(rmax - rmin) : 0u;
         a_rfix[lane] = (uint32_t)(c.half - rmin) - 0x4B400000u;
+        a_rmin[lane] = rmin;
         if (lane == 63) s_accbins = incl;
         // a table whose bins leave [0, numrho) is not OpenCV's: refuse
         if (lane < numangle && (rmin < 0 || rmax >= numrho)) atomicOr(status, 2);
@@ -757,11 +766,21 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     const int accbins = s_accbins, maskwords = s_maskwords;
     const size_t acc_off = ((size_t)(n + nrows) + 1) & ~(size_t)1;                 // in 32-bit words, 8-byte aligned
     const size_t acc_words = ((size_t)accbins + 1) / 2;
-    const size_t mask_off = (acc_off + acc_words + 1) & ~(size_t)1;
+    // the full-vote accumulator, when wanted, is a second array of the same compact shape (plain 16-bit counts)
+    bool full_here = acc_full != nullptr;
+    size_t facc_off = (acc_off + acc_words + 1) & ~(size_t)1;
+    size_t mask_off = full_here ? ((facc_off + acc_words + 1) & ~(size_t)1) : facc_off;
+    if (full_here && (mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes) {   // no room for it: the vote kernel does this frame
+        full_here = false;
+        mask_off = facc_off;
+    }
     if ((mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes || maskwords > 0xFFFF) {
-        if (tid == 0) fallback[f] = 1;   // does not fit the CU's LDS: the general kernel takes the frame
+        if (tid == 0) fallback[f] = 3;   // does not fit the CU's LDS: the general kernel (and the vote kernel) take the frame
         return;
     }
+    if (tid == 0) fallback[f] = (acc_full != nullptr && !full_here) ? 2 : 0;
+    if (full_here)
+        for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[facc_off + i] = 0;
     c.lacc = reinterpret_cast<int16_t *>(lds32 + acc_off);
     c.lmask = reinterpret_cast<uint64_t *>(lds32 + mask_off);
     c.rowtab = rowtab; c.ymin = ymin; c.nrows = nrows;
@@ -783,7 +802,44 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     vl.rfix = a_rfix[lane];
     vl.wid = a_wid[lane];
     vl.words = reinterpret_cast<uint32_t *>(c.lacc);
-    if (wave >= 2) {                // helpers: vote removal for accepted lines
+    if (wave >= 2) {                // helpers: the full-vote accumulator first, then vote removal for accepted lines
+        if (full_here) {
+            // every point votes once per angle (one angle per lane), straight from the sorted list in memory --
+            // the LDS copy is being permuted by the producer.  Counts stay below 2^14: plain 16-bit halves.
+            uint32_t *fw = lds32 + facc_off;
+            const int part = wave - 2, nparts = PPHT_THREADS / 64 - 2;
+            for (int p0 = part * 64; p0 < n; p0 += nparts * 64) {
+                const int m = min(64, n - p0);
+                const uint32_t ptv = lane < m ? nz[p0 + lane] : 0u;
+                const float fjv = (float)(ptv & 0xFFFF), fiv = (float)(ptv >> 16);
+                for (int t = 0; t < m; t++) {
+                    const float fj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), t));
+                    const float fi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), t));
+                    uint32_t widx, sh, over;
+                    vote_bin(vl, fj, fi, widx, sh, over);
+                    atomicAdd(&fw[widx], vl.one << sh);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(&vote_done, 1);
+            while (*(volatile int *)&vote_done < nparts) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // write-out in OpenCV's [angle][rho] shape: zeros outside the reachable range of an angle
+            for (int a = part; a < numangle; a += nparts) {
+                const int rmin = a_rmin[a], wid = (int)a_wid[a];
+                const uint32_t base = a_base[a];
+                int32_t *out = acc_full + ((size_t)f * numangle + a) * numrho;
+                for (int r = lane; r < numrho; r += 64) {
+                    const int k = r - rmin;
+                    int v = 0;
+                    if ((unsigned)k <= (unsigned)wid) {
+                        const uint32_t bin = base + (uint32_t)k;
+                        v = (int)((fw[bin >> 1] >> ((bin & 1u) << 4)) & 0xFFFFu);
+                    }
+                    out[r] = v;
+                }
+            }
+        }
         job_serve(&jobs, wave - 1, vl, lane);
         return;
     }
@@ -973,10 +1029,10 @@ void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, const int *row
 }
 
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
-                 int numangle, int numrho, int32_t *acc, hipStream_t st) {
+                 int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st) {
     (void)g;
     // angle rows per block: what fits 6 KiB of LDS, at least one.  Small on purpose: the kernel then shares
-    // CUs with the HoughLinesP kernel of the previous batch, which leaves only a few KiB of LDS free.
+    // CUs with the HoughLinesP kernel of another batch, which leaves only a few KiB of LDS free.
     int apg = (6 * 1024) / (numrho * 4);
     if (apg < 1) apg = 1;
     if (apg > numangle) apg = numangle;
@@ -988,33 +1044,42 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = lds;
     }
-    hipLaunchKernelGGL(k_vote, dim3(groups, nframes), dim3(256), lds, st, nz, nz_cap, npoints, tab, numangle, numrho, apg, acc);
+    // the flagged launch (few frames, if any, have work) is one block per frame: it must not queue thousands of
+    // blocks that only look at a flag behind the waves of the kernels it shares the GPU with
+    hipLaunchKernelGGL(k_vote, dim3(flags ? 1 : groups, nframes), dim3(256), lds, st, nz, nz_cap, npoints, tab, numangle, numrho, apg,
+                       acc, flags);
 }
 
-void launch_ppht(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
-                 const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
-                 int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, int *fallback,
-                 const uint32_t *rng_out, int rng_len, hipStream_t st) {
-    // fast path: points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not
-    // fit (the kernel decides, per frame) is flagged for the general kernel.  The kernel gets 144 of the
-    // CU's 160 KiB: the rest stays free for its own static tables and for the small kernels of the next
-    // batch (hysteresis closure, vote) that run beside it.
-    bool fast = false;
-    if (numangle <= 64 && g.W <= 16320) {
-        const int lds_bytes = 144 * 1024;
-        const int lds_points = std::min(rng_len, LDS_BIAS - 1);
-        static bool fast_attr = false;
-        if (!fast_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_fast), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            fast_attr = true;
-        }
-        hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(PPHT_THREADS), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
-                           numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, fallback, lds_points, rng_out,
-                           lds_bytes);
-        fast = true;
+// HoughLinesP in two steps, so that the caller can put the flagged vote kernel between them (the general
+// kernel permutes the point list in place).  flags[f]: bit 0 = the general kernel must do frame f,
+// bit 1 = the frame's full-vote accumulator (acc_full, may be null) was not produced here.
+bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
+                      const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
+                      int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
+                      int rng_len, int32_t *acc_full, hipStream_t st) {
+    // points, compact int16 accumulator(s) and the mask spans in LDS; a frame whose set does not fit (the
+    // kernel decides, per frame) is flagged.  The kernel may take 152 of the CU's 160 KiB: the rest covers
+    // its own static tables and the little LDS the short kernels of the next batch need beside it.
+    if (numangle > 64 || g.W > 16320) return false;
+    const int lds_bytes = 152 * 1024;
+    const int lds_points = std::min(rng_len, LDS_BIAS - 1);
+    static bool fast_attr = false;
+    if (!fast_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_fast), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        fast_attr = true;
     }
+    hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(PPHT_THREADS), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+                       numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
+                       lds_bytes, acc_full);
+    return true;
+}
+
+void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
+                         const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
+                         int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, const int *flags,
+                         hipStream_t st) {
     hipLaunchKernelGGL(k_ppht_general, dim3(nframes), dim3(256), 0, st, g, nz, nz_cap, npoints, rowplane, tab, numangle, numrho,
-                       acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, fast ? fallback : nullptr);
+                       acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags);
 }
 
 #ifdef LC_STAMPS
