@@ -110,6 +110,19 @@ struct Work {
     HoughGeo hg;
     double rho = 0, theta = 0;
     int seg_cap = 0;
+    // pipeline slots keep everything that goes back to the host after a batch in one block, so that one
+    // copy fetches it: [segment counts B][hysteresis rounds B][status, 7 spare][segments B * cap * 4]
+    DevBuf<int32_t> resblock;
+    size_t res_head = 0;
+    int32_t *r_segcount = nullptr, *r_rounds = nullptr, *r_status = nullptr, *r_seg = nullptr;
+    int init_results(int segcap) {
+        int rc;
+        res_head = 2 * (size_t)B + 8;
+        if ((rc = resblock.alloc(res_head + (size_t)B * segcap * 4))) return rc;
+        HIP_TRY(hipMemset(resblock.p, 0, sizeof(int32_t) * res_head));
+        r_segcount = resblock.p; r_rounds = resblock.p + B; r_status = resblock.p + 2 * (size_t)B; r_seg = resblock.p + res_head;
+        return LC_OK;
+    }
 
     int init_images(int W, int H, int batch, bool own_input, bool intermediates, bool colour) {
         g = make_geo(W, H);
@@ -130,6 +143,9 @@ struct Work {
         if ((rc = wake.alloc(2 * (size_t)B * g.TX * g.TY))) return rc;
         if ((rc = rounds.alloc(B))) return rc;
         if ((rc = rowcount.alloc((size_t)B * H))) return rc;
+        // both are left all zero by their last reader (hysteresis closure / point scatter), so once is enough
+        HIP_TRY(hipMemset(wake.p, 0, sizeof(uint32_t) * 2 * (size_t)B * g.TX * g.TY));
+        HIP_TRY(hipMemset(rowcount.p, 0, sizeof(int) * (size_t)B * H));
         if ((rc = rowoff.alloc((size_t)B * H))) return rc;
         if ((rc = npoints.alloc(B))) return rc;
         if ((rc = segcount.alloc(B))) return rc;
@@ -229,7 +245,7 @@ int points_from_bytes(lc_ctx *ctx, int *npoints_host) {
     Work &w = ctx->work;
     hipStream_t st = ctx->stream;
     launch_pack_nonzero(ctx->tmpA.p, w.g, 1, w.rowplane.p, w.rowcount.p, st);
-    launch_rowscan(w.g, 1, w.rowcount.p, w.rowoff.p, w.npoints.p, st);
+    launch_rowscan(w.g, 1, w.rowcount.p, w.rowoff.p, w.npoints.p, nullptr, st);
     launch_scatter(w.g, 1, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, st);
     if (npoints_host) {
         HIP_TRY(hipMemcpyAsync(npoints_host, w.npoints.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -577,7 +593,8 @@ struct Slot {
     const uint8_t *input = nullptr;   // device pointer of the frames of the batch in flight
     size_t input_bytes = 0;
     bool busy = false, timed = false;
-    // pinned host staging
+    // pinned host mirror of the slot's result block
+    int32_t *h_res = nullptr;
     int *h_rounds = nullptr, *h_status = nullptr, *h_segcount = nullptr;
     int32_t *h_seg = nullptr;
 };
@@ -603,6 +620,14 @@ struct lc_pipe {
     //             CU's LDS: on a high-priority stream the dispatcher places it ahead of the next batch's
     //             front-end waves instead of behind them.
     hipStream_t st_up = nullptr, st_edge = nullptr, st_lines = nullptr;
+    // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs), while the short
+    // latency-bound kernels behind the front end leave the GPU half empty.  So the HoughLinesP step of a batch
+    // is not queued when the batch is submitted but when the NEXT one is, behind that batch's front-end kernel:
+    // it then runs beside the next batch's hysteresis / finalize / compaction and only the rest of it beside a
+    // front end.  `deferred` is the slot whose HoughLinesP step is still to be queued (-1: none); waiting for
+    // that slot queues it at once.  defer_after: 0 = never defer, 1 = behind the front end, 2 = behind hysteresis.
+    int deferred = -1;
+    int defer_after = 1;
     std::vector<Slot> slots;
 };
 
@@ -610,18 +635,20 @@ namespace {
 
 enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END, EV_ESTART, EV_LSTART, EV_VSTART };
 
+void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after);
+
 void enqueue_back(lc_pipe *pp, Slot &s) {
     Work &w = s.w;
     const lc_pipe_params &p = pp->p;
     const int n = s.nframes;
     hipStream_t es = pp->st_edge;
-    (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);
+    const bool hough = p.want_accumulator || p.want_segments;
+    if (!hough) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
                     w.rowplane.p, w.rowcount.p, es);
     (void)hipEventRecord(s.ev[EV_EDGE], es);
-    const bool hough = p.want_accumulator || p.want_segments;
     if (hough) {
-        launch_rowscan(w.g, n, w.rowcount.p, w.rowoff.p, w.npoints.p, es);
+        launch_rowscan(w.g, n, w.rowcount.p, w.rowoff.p, w.npoints.p, w.r_status, es);
         launch_scatter(w.g, n, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, es);
     }
     (void)hipEventRecord(s.ev[EV_POINTS], es);
@@ -633,14 +660,25 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     if (p.want_accumulator && !vote_fused)
         launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, nullptr, es);
     if (!vote_fused) (void)hipEventRecord(s.ev[EV_VOTE], es);
+    if (p.want_segments && pp->st_lines != es && pp->defer_after && pp->slots.size() > 1) pp->deferred = (int)(&s - &pp->slots[0]);
+    else enqueue_lines(pp, s, nullptr);
+}
+
+// HoughLinesP step and the copy of the batch's results; `after` (may be null) is a later batch's event to start behind
+void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
+    Work &w = s.w;
+    const lc_pipe_params &p = pp->p;
+    const int n = s.nframes;
+    hipStream_t es = pp->st_edge;
+    const bool vote_fused = p.want_accumulator && p.want_segments;
     hipStream_t ls = es;   // the stream the batch finishes on
     if (p.want_segments) {
         ls = pp->st_lines;
         if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[EV_POINTS], 0);
+        if (ls != es && after) (void)hipStreamWaitEvent(ls, after, 0);
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
-        (void)hipMemsetAsync(w.status.p, 0, sizeof(int), ls);
         const bool fast = launch_ppht_fast(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
-                                           p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p,
+                                           p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
                                            w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls);
         if (vote_fused) {
             (void)hipEventRecord(s.ev[EV_VSTART], ls);
@@ -649,17 +687,16 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
             (void)hipEventRecord(s.ev[EV_VOTE], ls);
         }
         launch_ppht_general(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
-                            p.threshold, pp->line_length, pp->line_gap, w.seg.p, w.seg_cap, w.segcount.p, w.status.p,
+                            p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
                             fast ? w.fallback.p : nullptr, ls);
         (void)hipEventRecord(s.ev[EV_LINES], ls);
-        (void)hipMemcpyAsync(s.h_segcount, w.segcount.p, sizeof(int) * n, hipMemcpyDeviceToHost, ls);
-        (void)hipMemcpyAsync(s.h_seg, w.seg.p, sizeof(int32_t) * 4 * (size_t)n * w.seg_cap, hipMemcpyDeviceToHost, ls);
-        (void)hipMemcpyAsync(s.h_status, w.status.p, sizeof(int), hipMemcpyDeviceToHost, ls);
     } else {
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
         (void)hipEventRecord(s.ev[EV_LINES], ls);
     }
-    (void)hipMemcpyAsync(s.h_rounds, w.rounds.p, sizeof(int) * n, hipMemcpyDeviceToHost, ls);
+    // one copy: counts, rounds, status and (if wanted) the segments of the n frames
+    const size_t res_ints = w.res_head + (p.want_segments ? (size_t)n * w.seg_cap * 4 : 0);
+    (void)hipMemcpyAsync(s.h_res, w.resblock.p, sizeof(int32_t) * res_ints, hipMemcpyDeviceToHost, ls);
     (void)hipEventRecord(s.ev[EV_END], ls);
 }
 
@@ -680,8 +717,10 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
-    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.rounds.p, es);
+    if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
+    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, es);
     HIP_TRY(hipEventRecord(s.ev[EV_HYST], es));
+    if (pp->deferred >= 0) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_HYST]); pp->deferred = -1; }
     enqueue_back(pp, s);
     HIP_TRY(hipGetLastError());
     s.busy = true;
@@ -756,6 +795,8 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     {
         hipError_t e = hipStreamCreateWithFlags(&pp->st_up, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp->st_edge, hipStreamNonBlocking);
+        const char *da = getenv("LANECV_LINES_DEFER");      // diagnostics: 0 / 1 / 2, see defer_after
+        if (da && da[0] >= '0' && da[0] <= '2') pp->defer_after = da[0] - '0';
         const char *pr = getenv("LANECV_LINES_PRIORITY");   // diagnostics: 0 keeps HoughLinesP on the edge stream
         if (e == hipSuccess && p.want_segments && !(pr && pr[0] == '0')) {
             int lo_pri = 0, hi_pri = 0;
@@ -782,16 +823,16 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
                 return rc;
             }
         }
+        const int segcap = std::max(p.seg_capacity, 1);
+        s.w.seg_cap = segcap;
+        if ((rc = s.w.init_results(segcap))) { lc_pipe_destroy(pp); return rc; }
         void *hp = nullptr;
-        if ((rc = lc_host_alloc_pinned(sizeof(int) * p.max_batch, &hp))) { lc_pipe_destroy(pp); return rc; }
-        s.h_rounds = (int *)hp;
-        if ((rc = lc_host_alloc_pinned(sizeof(int), &hp))) { lc_pipe_destroy(pp); return rc; }
-        s.h_status = (int *)hp;
-        *s.h_status = 0;
-        if ((rc = lc_host_alloc_pinned(sizeof(int) * p.max_batch, &hp))) { lc_pipe_destroy(pp); return rc; }
-        s.h_segcount = (int *)hp;
-        if ((rc = lc_host_alloc_pinned(sizeof(int32_t) * 4 * (size_t)p.max_batch * std::max(p.seg_capacity, 1), &hp))) { lc_pipe_destroy(pp); return rc; }
-        s.h_seg = (int32_t *)hp;
+        const size_t res_ints = s.w.res_head + (size_t)p.max_batch * segcap * 4;
+        if ((rc = lc_host_alloc_pinned(sizeof(int32_t) * res_ints, &hp))) { lc_pipe_destroy(pp); return rc; }
+        s.h_res = (int32_t *)hp;
+        memset(s.h_res, 0, sizeof(int32_t) * s.w.res_head);
+        s.h_segcount = s.h_res; s.h_rounds = s.h_res + p.max_batch; s.h_status = s.h_res + 2 * (size_t)p.max_batch;
+        s.h_seg = s.h_res + s.w.res_head;
     }
     *out = pp;
     return LC_OK;
@@ -800,16 +841,17 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
 int lc_pipe_destroy(lc_pipe *pipe) {
     if (!pipe) return LC_OK;
     (void)hipSetDevice(pipe->ctx->device);
+    if (pipe->deferred >= 0 && pipe->st_lines) { enqueue_lines(pipe, pipe->slots[pipe->deferred], nullptr); pipe->deferred = -1; }
+    if (pipe->st_up) (void)hipStreamSynchronize(pipe->st_up);
+    if (pipe->st_edge) (void)hipStreamSynchronize(pipe->st_edge);
+    if (pipe->st_lines) (void)hipStreamSynchronize(pipe->st_lines);
     for (Slot &s : pipe->slots) {
         for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
-        if (s.h_rounds) (void)hipHostFree(s.h_rounds);
-        if (s.h_status) (void)hipHostFree(s.h_status);
-        if (s.h_segcount) (void)hipHostFree(s.h_segcount);
-        if (s.h_seg) (void)hipHostFree(s.h_seg);
+        if (s.h_res) (void)hipHostFree(s.h_res);
     }
-    if (pipe->st_lines && pipe->st_lines != pipe->st_edge) { (void)hipStreamSynchronize(pipe->st_lines); (void)hipStreamDestroy(pipe->st_lines); }
-    if (pipe->st_edge) { (void)hipStreamSynchronize(pipe->st_edge); (void)hipStreamDestroy(pipe->st_edge); }
-    if (pipe->st_up) { (void)hipStreamSynchronize(pipe->st_up); (void)hipStreamDestroy(pipe->st_up); }
+    if (pipe->st_lines && pipe->st_lines != pipe->st_edge) (void)hipStreamDestroy(pipe->st_lines);
+    if (pipe->st_edge) (void)hipStreamDestroy(pipe->st_edge);
+    if (pipe->st_up) (void)hipStreamDestroy(pipe->st_up);
     delete pipe;
     return LC_OK;
 }
@@ -846,6 +888,7 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     int rc;
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
+    if (pipe->deferred == slot) { enqueue_lines(pipe, *s, nullptr); pipe->deferred = -1; }
     HIP_TRY(hipEventSynchronize(s->ev[EV_END]));
     s->busy = false;
     const lc_pipe_params &p = pipe->p;

@@ -547,9 +547,9 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st) {
-    // wake holds two flag arrays of nframes * tiles words each
+    // wake holds two flag arrays of nframes * tiles words each.  They are all zero on entry (zeroed when
+    // allocated) and again on exit: the closure clears every flag it consumes and stops when a round sets none.
     const int per = g.TX * g.TY, nt = per * nframes;
-    (void)hipMemsetAsync(wake, 0, sizeof(uint32_t) * 2 * (size_t)nt, st);
     hipLaunchKernelGGL(k_hyst_first, dim3((nt + HY_WAVES - 1) / HY_WAVES), dim3(64 * HY_WAVES), 0, st, g, nt, planeS, planeW, wake);
     hipLaunchKernelGGL(k_hyst_close, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds);
 }

@@ -19,9 +19,10 @@ __device__ __forceinline__ int rho_bin(int x, int y, float c, float s, int half)
 
 // exclusive scan of the per-row point counts of one frame
 __global__ __launch_bounds__(256) void k_rowscan(int H, const int *__restrict__ rowcount, int *__restrict__ rowoff,
-                                                 int *__restrict__ npoints) {
+                                                 int *__restrict__ npoints, int *__restrict__ status) {
     __shared__ int part[256];
     const int f = blockIdx.x, tid = threadIdx.x;
+    if (status && f == 0 && tid == 0) *status = 0;   // the Hough kernels behind this one OR their error bits into it
     const int per = (H + 255) / 256;
     const int r0 = tid * per, r1 = min(H, r0 + per);
     int s = 0;
@@ -46,12 +47,13 @@ __global__ __launch_bounds__(256) void k_rowscan(int H, const int *__restrict__ 
 // (most of the image outside the ROI) leave at once; otherwise lane l takes word l of the row, a
 // wave scan of the popcounts places each word's points.
 __global__ __launch_bounds__(256) void k_scatter(Geo g, int nframes, const uint64_t *__restrict__ rowplane,
-                                                 const int *__restrict__ rowcount, const int *__restrict__ rowoff,
+                                                 int *__restrict__ rowcount, const int *__restrict__ rowoff,
                                                  uint32_t *__restrict__ nz, int nz_cap) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long long)nframes * g.H) return;
     if (rowcount[row] == 0) return;
+    if (lane == 0) rowcount[row] = 0;      // last reader: the counts are zero again for the next batch
     const int f = (int)(row / g.H), y = (int)(row % g.H);
     int off = rowoff[row];
     uint32_t *out = nz + (size_t)f * nz_cap;
@@ -1017,11 +1019,11 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
 
 }  // namespace
 
-void launch_rowscan(Geo g, int nframes, const int *rowcount, int *rowoff, int *npoints, hipStream_t st) {
-    hipLaunchKernelGGL(k_rowscan, dim3(nframes), dim3(256), 0, st, g.H, rowcount, rowoff, npoints);
+void launch_rowscan(Geo g, int nframes, const int *rowcount, int *rowoff, int *npoints, int *status, hipStream_t st) {
+    hipLaunchKernelGGL(k_rowscan, dim3(nframes), dim3(256), 0, st, g.H, rowcount, rowoff, npoints, status);
 }
 
-void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, const int *rowcount, const int *rowoff, uint32_t *nz,
+void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, const int *rowoff, uint32_t *nz,
                     int nz_cap, hipStream_t st) {
     long long rows = (long long)nframes * g.H;
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, g, nframes, rowplane, rowcount, rowoff, nz,
