@@ -183,21 +183,26 @@ struct Ppht {
     int16_t *lacc;             // LDS accumulator (fast path)
     int32_t *acc;              // global accumulator (general path)
     int32_t *seg;
-    // fast path: the frame's edge bits live in LDS, only the word span of every row that has points
+    // fast path: the frame's edge bits live in LDS, only the 64-pixel words that hold a point
     const AngleEntry *ltab;    // LDS copy of tab (walk steps of every angle)
-    uint64_t *lmask;           // the spans, back to back
-    const uint32_t *rowtab;    // per row ymin + r: first LDS word (bits 0-15), first image word (16-23), words (24-31)
+    uint64_t *lmask;           // those words, row after row
+    const uint4 *rowtab;       // per row ymin + r: x = LDS index of the row's first word, (z, w) = which of the row's 64 words are kept
     int ymin, nrows;
 };
+
+// LDS word of image word wi of a row-table entry; false if that word holds no point (all zero)
+__device__ __forceinline__ bool row_word(const uint4 &e, int wi, uint32_t &widx) {
+    const uint64_t bm = (uint64_t)e.z | ((uint64_t)e.w << 32);
+    widx = e.x + (uint32_t)__popcll(bm & ((1ull << wi) - 1));
+    return (bm >> wi) & 1;
+}
 
 // Edge bit of pixel (j, i) in the LDS copy; widx is the LDS word that holds it (valid when the result is true).
 __device__ __forceinline__ bool lds_mask_bit(const Ppht &c, int j, int i, uint32_t &widx) {
     const unsigned r = (unsigned)(i - c.ymin);
     if (r >= (unsigned)c.nrows) return false;
-    const uint32_t e = c.rowtab[r];
-    const unsigned wi = (unsigned)(j >> 6) - ((e >> 16) & 0xFFu);
-    if (wi >= (e >> 24)) return false;
-    widx = (e & 0xFFFFu) + wi;
+    const uint4 e = c.rowtab[r];
+    if (!row_word(e, j >> 6, widx)) return false;
     return (c.lmask[widx] >> (j & 63)) & 1;
 }
 
@@ -305,7 +310,7 @@ __device__ __forceinline__ void fetch_chunks(const Ppht &c, const Walk &wk, int 
     bool inb[2][N];
     int sh[2][N];
     if constexpr (LDS_STATE) {
-        uint32_t ent[2][N];
+        uint4 ent[2][N];
         int wcol[2][N];
 #pragma unroll
         for (int k = 0; k < 2; k++)
@@ -324,12 +329,11 @@ __device__ __forceinline__ void fetch_chunks(const Ppht &c, const Walk &wk, int 
         for (int k = 0; k < 2; k++)
 #pragma unroll
             for (int q = 0; q < N; q++) {
-                const uint32_t e = ent[k][q];
-                const unsigned wi = (unsigned)wcol[k][q] - ((e >> 16) & 0xFFu);
-                const bool in_span = wcol[k][q] >= 0 && wi < (e >> 24);
-                wword[k][q] = in_span ? (e & 0xFFFFu) + wi : 0u;
+                uint32_t widx;
+                const bool kept = row_word(ent[k][q], wcol[k][q] & 63, widx) && wcol[k][q] >= 0;
+                wword[k][q] = kept ? widx : 0u;
                 wv[k][q] = c.lmask[wword[k][q]];
-                if (!in_span) sh[k][q] = -1;
+                if (!kept) sh[k][q] = -1;
             }
 #pragma unroll
         for (int k = 0; k < 2; k++)
@@ -669,20 +673,25 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     c.seg = seg_all + (size_t)f * seg_cap * 4;
 
     // ---- set-up: everything the loop touches moves into LDS ------------------------------------
-    // layout: [points n][row table nrows][accumulator][mask spans]
+    // layout: [points n][row table nrows x 16 B][accumulator][full-vote accumulator][mask words]
     // The points arrive sorted by row, then column.  Only bins a pixel of the points' bounding box can
-    // reach are kept of every angle's accumulator row, and only the words between the first and the
-    // last point of every row of the mask -- together a fraction of the full arrays.
+    // reach are kept of every angle's accumulator row, and of the mask only the 64-pixel words that hold
+    // a point (a 64-bit map per row says which) -- together a fraction of the full arrays.
     uint32_t *lnz = lds32;
     const int ymin = (int)(nz[0] >> 16), ymax = (int)(nz[n - 1] >> 16);
     const int nrows = ymax - ymin + 1;
-    uint32_t *rowtab = lds32 + n;
+    const size_t rt_off = ((size_t)n + 3) & ~(size_t)3;          // 16-byte aligned
+    uint32_t *rowtab = lds32 + rt_off;
+    if ((rt_off + 4 * (size_t)nrows) * 4 > (size_t)lds_bytes) {  // (the row table alone does not fit)
+        if (tid == 0) fallback[f] = 3;
+        return;
+    }
     if (tid == 0) {
         progress = 0; vote_done = 0;
         jobs.seq = 0; jobs.done = 0;
         s_xmin = INT_MAX; s_xmax = 0;
     }
-    for (int r = tid; r < nrows; r += PPHT_THREADS) rowtab[r] = 0;
+    for (int r = tid; r < 4 * nrows; r += PPHT_THREADS) rowtab[r] = 0;
     if (tid < numangle) s_tab[tid] = tab[tid];
     __syncthreads();
     {
@@ -702,23 +711,19 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     }
     __syncthreads();
     for (int i = tid; i < n; i += PPHT_THREADS) {
-        // first / last point of its row: they bound the row's span (bit 0 marks a row that has points)
+        // the first point of every 64-pixel word marks the word in its row's map
         const uint32_t pt = lnz[i];
-        const int x = (int)(pt & 0xFFFF), y = (int)(pt >> 16);
-        const bool first = i == 0 || (int)(lnz[i - 1] >> 16) != y;
-        const bool last = i == n - 1 || (int)(lnz[i + 1] >> 16) != y;
-        if (first) atomicOr(&rowtab[y - ymin], 1u | ((uint32_t)(x >> 6) << 16));
-        if (last) atomicOr(&rowtab[y - ymin], (uint32_t)(x >> 6) << 24);
+        const int wi = (int)(pt & 0xFFFF) >> 6, y = (int)(pt >> 16);
+        const uint32_t pv = i ? lnz[i - 1] : 0u;
+        if (i == 0 || (int)(pv >> 16) != y || ((int)(pv & 0xFFFF) >> 6) != wi)
+            atomicOr(&rowtab[4 * (y - ymin) + 2 + (wi >> 5)], 1u << (wi & 31));
     }
     __syncthreads();
-    {   // exclusive scan of the span lengths over the rows -> first LDS word of every row
+    {   // exclusive scan of the kept-word counts over the rows -> LDS index of every row's first word
         const int per = (nrows + PPHT_THREADS - 1) / PPHT_THREADS;
         const int r0 = tid * per, r1 = min(nrows, r0 + per);
         int sum = 0;
-        for (int r = r0; r < r1; r++) {
-            const uint32_t e = rowtab[r];
-            if (e & 1u) sum += (int)(e >> 24) - (int)((e >> 16) & 0xFFu) + 1;
-        }
+        for (int r = r0; r < r1; r++) sum += __popc(rowtab[4 * r + 2]) + __popc(rowtab[4 * r + 3]);
         s_part[tid] = sum;
         __syncthreads();
         for (int d = 1; d < PPHT_THREADS; d <<= 1) {
@@ -729,14 +734,8 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
         }
         int off = s_part[tid] - sum;
         for (int r = r0; r < r1; r++) {
-            const uint32_t e = rowtab[r];
-            uint32_t out = 0;
-            if (e & 1u) {
-                const uint32_t w0 = (e >> 16) & 0xFFu, nw = (e >> 24) - w0 + 1;
-                out = ((uint32_t)off & 0xFFFFu) | (w0 << 16) | (nw << 24);
-                off += (int)nw;
-            }
-            rowtab[r] = out;
+            rowtab[4 * r] = (uint32_t)off;
+            off += __popc(rowtab[4 * r + 2]) + __popc(rowtab[4 * r + 3]);
         }
         if (tid == PPHT_THREADS - 1) s_maskwords = s_part[tid];
     }
@@ -766,7 +765,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     }
     __syncthreads();
     const int accbins = s_accbins, maskwords = s_maskwords;
-    const size_t acc_off = ((size_t)(n + nrows) + 1) & ~(size_t)1;                 // in 32-bit words, 8-byte aligned
+    const size_t acc_off = rt_off + 4 * (size_t)nrows;                             // in 32-bit words, 16-byte aligned
     const size_t acc_words = ((size_t)accbins + 1) / 2;
     // the full-vote accumulator, when wanted, is a second array of the same compact shape (plain 16-bit counts)
     bool full_here = acc_full != nullptr;
@@ -776,7 +775,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
         full_here = false;
         mask_off = facc_off;
     }
-    if ((mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes || maskwords > 0xFFFF) {
+    if ((mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes) {
         if (tid == 0) fallback[f] = 3;   // does not fit the CU's LDS: the general kernel (and the vote kernel) take the frame
         return;
     }
@@ -785,14 +784,13 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
         for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[facc_off + i] = 0;
     c.lacc = reinterpret_cast<int16_t *>(lds32 + acc_off);
     c.lmask = reinterpret_cast<uint64_t *>(lds32 + mask_off);
-    c.rowtab = rowtab; c.ymin = ymin; c.nrows = nrows;
+    c.rowtab = reinterpret_cast<const uint4 *>(rowtab); c.ymin = ymin; c.nrows = nrows;
     c.ltab = s_tab;
     for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[acc_off + i] = (uint32_t)LDS_BIAS * 0x10001u;
-    for (int r = wave; r < nrows; r += PPHT_THREADS / 64) {
-        const uint32_t e = rowtab[r];
-        const int nw = (int)(e >> 24);
-        const uint64_t *src = c.mask + (size_t)(ymin + r) * c.TX + ((e >> 16) & 0xFFu);
-        for (int l = lane; l < nw; l += 64) c.lmask[(e & 0xFFFFu) + l] = src[l];
+    for (int r = wave; r < nrows; r += PPHT_THREADS / 64) {     // lane = image word of the row
+        const uint4 e = c.rowtab[r];
+        uint32_t widx;
+        if (row_word(e, lane, widx)) c.lmask[widx] = c.mask[(size_t)(ymin + r) * c.TX + lane];
     }
     __syncthreads();
     // lane l votes for angle l; lanes past the last angle add zero to a harmless bin instead of branching
@@ -1062,7 +1060,7 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
     // points, compact int16 accumulator(s) and the mask spans in LDS; a frame whose set does not fit (the
     // kernel decides, per frame) is flagged.  The kernel may take 152 of the CU's 160 KiB: the rest covers
     // its own static tables and the little LDS the short kernels of the next batch need beside it.
-    if (numangle > 64 || g.W > 16320) return false;
+    if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
     const int lds_bytes = 152 * 1024;
     const int lds_points = std::min(rng_len, LDS_BIAS - 1);
     static bool fast_attr = false;
