@@ -1044,10 +1044,10 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = lds;
     }
-    // the flagged launch (few frames, if any, have work) is one block per frame: it must not queue thousands of
+    // the flagged launch (often no frame has work) is at most 8 blocks per frame: it must not queue thousands of
     // blocks that only look at a flag behind the waves of the kernels it shares the GPU with
-    hipLaunchKernelGGL(k_vote, dim3(flags ? 1 : groups, nframes), dim3(256), lds, st, nz, nz_cap, npoints, tab, numangle, numrho, apg,
-                       acc, flags);
+    hipLaunchKernelGGL(k_vote, dim3(flags ? std::min(groups, 8) : groups, nframes), dim3(256), lds, st, nz, nz_cap, npoints, tab, numangle,
+                       numrho, apg, acc, flags);
 }
 
 // HoughLinesP in two steps, so that the caller can put the flagged vote kernel between them (the general
