@@ -1,0 +1,116 @@
+"""Host-side glue behind HoughLinesP: what the lane scripts do with the segments.
+
+Pure NumPy, no GPU work: a frame's segment list is a few hundred bytes.  Each function follows one of the
+reference's post-Hough blocks and keeps its observable quirks:
+
+* a segment's slope is ``(y2 - y1) / (x2 - x1)`` on NumPy integers, so a vertical segment has slope +-inf
+  (or nan for a zero-length one) instead of raising; ``abs(slope) < limit`` drops near-horizontal segments,
+  ``slope <= 0`` sends a segment to the left lane, anything else -- +inf and nan included -- to the right
+  (`Simple Lane Detection with OpenCV_2(images).py:101-113`);
+* both end points of every kept segment enter a least-squares fit of x as a polynomial in y (`np.polyfit`,
+  the routine the scripts call), evaluated at the bottom row and at 3/5 of the height and truncated with
+  ``int()`` (`..._2(images).py:116-143`);
+* the video scripts smooth over frames with alpha = 0.1: `..._4(mp4).py:144-178` averages the four integers of
+  each lane line (truncating again), `..._5(mp4).py:108-138` the three coefficients of a degree-2 fit.
+"""
+import numpy as np
+
+__all__ = ["split_by_slope", "lane_lines", "LineSmoother", "CurveSmoother"]
+
+
+def split_by_slope(lines, min_abs_slope=0.5):
+    """lines: what HoughLinesP returns -- ``(N, 1, 4)`` int32 or None.  Returns four 1-D int arrays
+    ``(left_x, left_y, right_x, right_y)`` holding both end points of the kept segments, in segment order."""
+    empty = np.zeros(0, dtype=np.int64)
+    if lines is None:
+        return empty, empty, empty, empty
+    seg = np.asarray(lines).reshape(-1, 4).astype(np.int64)
+    x1, y1, x2, y2 = seg[:, 0], seg[:, 1], seg[:, 2], seg[:, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        slope = (y2 - y1) / (x2 - x1)
+    keep = ~(np.abs(slope) < min_abs_slope)          # nan compares False, as in the scripts: it stays
+    left = keep & (slope <= 0)
+    right = keep & ~(slope <= 0)
+
+    def both_ends(a, b, sel):
+        return np.stack([a[sel], b[sel]], axis=1).reshape(-1)
+
+    return both_ends(x1, x2, left), both_ends(y1, y2, left), both_ends(x1, x2, right), both_ends(y1, y2, right)
+
+
+def _fit_line(xs, ys, max_y, min_y):
+    """[x at max_y, max_y, x at min_y, min_y] of the degree-1 fit x(y), or None without points."""
+    if len(xs) == 0:
+        return None
+    poly = np.poly1d(np.polyfit(ys, xs, deg=1))
+    return [int(poly(max_y)), max_y, int(poly(min_y)), min_y]
+
+
+def lane_lines(lines, height, min_abs_slope=0.5):
+    """The two lane lines of `..._2(images).py:116-153`: ``[[xl_start, max_y, xl_end, min_y], [xr_start, max_y,
+    xr_end, min_y]]`` with max_y = height and min_y = int(height * 3 / 5); a side without segments gives x = 0."""
+    lx, ly, rx, ry = split_by_slope(lines, min_abs_slope)
+    min_y, max_y = int(height * (3 / 5)), int(height)
+    left = _fit_line(lx, ly, max_y, min_y) or [0, max_y, 0, min_y]
+    right = _fit_line(rx, ry, max_y, min_y) or [0, max_y, 0, min_y]
+    return [left, right]
+
+
+class LineSmoother:
+    """Frame-to-frame average of the two lane lines (`..._4(mp4).py:144-178`): the first line seen on a side is
+    taken as is, later ones enter as ``int(prev * (1 - alpha) + curr * alpha)`` per integer; a frame without
+    segments on a side leaves that side's line unchanged."""
+
+    def __init__(self, alpha=0.1, min_abs_slope=0.3):
+        self.alpha, self.min_abs_slope = alpha, min_abs_slope
+        self.left = None
+        self.right = None
+
+    def _blend(self, prev, curr):
+        if curr is None:
+            return prev
+        if prev is None:
+            return curr
+        a = self.alpha
+        return [int(p * (1 - a) + c * a) for p, c in zip(prev, curr)]
+
+    def update(self, lines, height):
+        """Returns the list of lines to draw (0, 1 or 2 entries, left first)."""
+        lx, ly, rx, ry = split_by_slope(lines, self.min_abs_slope)
+        min_y, max_y = int(height * (3 / 5)), int(height)
+        self.left = self._blend(self.left, _fit_line(lx, ly, max_y, min_y))
+        self.right = self._blend(self.right, _fit_line(rx, ry, max_y, min_y))
+        return [ln for ln in (self.left, self.right) if ln is not None]
+
+
+class CurveSmoother:
+    """Degree-2 fit x(y) per side with the coefficients averaged over frames (`..._5(mp4).py:108-138`).  A fit
+    that NumPy refuses (the scripts swallow the exception) counts as no fit for that frame."""
+
+    def __init__(self, alpha=0.1, min_abs_slope=0.3):
+        self.alpha, self.min_abs_slope = alpha, min_abs_slope
+        self.left = None
+        self.right = None
+
+    @staticmethod
+    def _fit(xs, ys):
+        if len(xs) == 0:
+            return None
+        try:
+            return np.polyfit(ys, xs, 2)
+        except Exception:
+            return None
+
+    def _blend(self, prev, curr):
+        if curr is None:
+            return prev
+        if prev is None:
+            return curr
+        return prev * (1 - self.alpha) + curr * self.alpha
+
+    def update(self, lines):
+        """Returns ``(left_coefficients, right_coefficients)``; a side never seen yet is None."""
+        lx, ly, rx, ry = split_by_slope(lines, self.min_abs_slope)
+        self.left = self._blend(self.left, self._fit(lx, ly))
+        self.right = self._blend(self.right, self._fit(rx, ry))
+        return self.left, self.right

@@ -1,0 +1,113 @@
+"""Post-Hough glue (`lanecv.glue`) against a per-segment loop written the way the lane scripts do it
+(`Simple Lane Detection with OpenCV_2(images).py:94-153`, `_4(mp4).py:120-178`, `_5(mp4).py:86-138`).
+Host-only: no GPU, no oracle."""
+import math
+import warnings
+
+import numpy as np
+import pytest
+
+from lanecv import glue
+
+
+def _loop_split(lines, limit):
+    lx, ly, rx, ry = [], [], [], []
+    if lines is not None:
+        for line in lines:
+            for x1, y1, x2, y2 in line:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    slope = (y2 - y1) / (x2 - x1)
+                if math.fabs(slope) < limit:
+                    continue
+                if slope <= 0:
+                    lx.extend([x1, x2]); ly.extend([y1, y2])
+                else:
+                    rx.extend([x1, x2]); ry.extend([y1, y2])
+    return lx, ly, rx, ry
+
+
+def _segments(rng, n, w=960, h=540):
+    seg = np.stack([rng.integers(0, w, n), rng.integers(h // 2, h, n), rng.integers(0, w, n), rng.integers(h // 2, h, n)], axis=1)
+    return seg.astype(np.int32).reshape(-1, 1, 4)
+
+
+def test_split_matches_the_loop_including_vertical_and_degenerate_segments():
+    rng = np.random.default_rng(5)
+    lines = _segments(rng, 200)
+    lines[3, 0] = [100, 300, 100, 500]      # vertical, downwards: +inf -> right
+    lines[4, 0] = [100, 500, 100, 300]      # vertical, upwards: -inf -> left
+    lines[5, 0] = [250, 400, 250, 400]      # zero length: nan -> kept, right
+    lines[6, 0] = [10, 300, 400, 310]       # nearly horizontal: dropped
+    for limit in (0.5, 0.3):
+        got = glue.split_by_slope(lines, limit)
+        want = _loop_split(lines, limit)
+        for g, w in zip(got, want):
+            assert list(g) == [int(v) for v in w]
+    assert all(len(a) == 0 for a in glue.split_by_slope(None))
+    lx, ly, rx, ry = glue.split_by_slope(lines[3:6], 0.5)
+    assert list(lx) == [100, 100] and list(ly) == [500, 300]
+    assert list(rx) == [100, 100, 250, 250] and list(ry) == [300, 500, 400, 400]
+
+
+def test_lane_lines_of_the_image_script():
+    rng = np.random.default_rng(6)
+    h = 540
+    for trial in range(20):
+        lines = _segments(rng, int(rng.integers(1, 40)))
+        lx, ly, rx, ry = _loop_split(lines, 0.5)
+        min_y, max_y = int(h * (3 / 5)), int(h)
+        want = []
+        for xs, ys in ((lx, ly), (rx, ry)):
+            if xs and ys:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    poly = np.poly1d(np.polyfit(ys, xs, deg=1))
+                want.append([int(poly(max_y)), max_y, int(poly(min_y)), min_y])
+            else:
+                want.append([0, max_y, 0, min_y])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert glue.lane_lines(lines, h) == want
+    assert glue.lane_lines(None, h) == [[0, 540, 0, 324], [0, 540, 0, 324]]
+    # two clean lanes: the fitted lines pass through them
+    lanes = np.array([[[200, 540, 400, 340]], [[760, 540, 560, 340]]], np.int32)
+    left, right = glue.lane_lines(lanes, 540)     # int() truncates, so an exact 200.0 may come out as 199
+    assert abs(left[0] - 200) <= 1 and abs(left[2] - 416) <= 1 and left[1::2] == [540, 324]
+    assert abs(right[0] - 760) <= 1 and abs(right[2] - 544) <= 1 and right[1::2] == [540, 324]
+
+
+def test_line_smoother_keeps_the_last_line_and_truncates():
+    sm = glue.LineSmoother(alpha=0.1)
+    lanes = np.array([[[200, 540, 400, 340]], [[760, 540, 560, 340]]], np.int32)
+    assert sm.update(None, 540) == []
+    first = sm.update(lanes, 540)
+    assert first == glue.lane_lines(lanes, 540)  # the first line of a side is taken as it is
+    shifted = lanes + np.array([37, 0, 37, 0], np.int32)
+    cur = glue.lane_lines(shifted, 540)
+    second = sm.update(shifted, 540)
+    assert second == [[int(p * 0.9 + c * 0.1) for p, c in zip(first[k], cur[k])] for k in range(2)]
+    only_right = shifted[1:]
+    third = sm.update(only_right, 540)
+    assert third[0] == second[0]                 # no left segments: the left line stays
+    assert third[1] == [int(p * 0.9 + c * 0.1) for p, c in zip(second[1], cur[1])]
+
+
+def test_curve_smoother_blends_coefficients():
+    rng = np.random.default_rng(8)
+    sm = glue.CurveSmoother(alpha=0.1)
+    assert sm.update(None) == (None, None)
+    prev = [None, None]
+    for frame in range(5):
+        lines = _segments(rng, 30)
+        lx, ly, rx, ry = _loop_split(lines, 0.3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cur = [np.polyfit(ly, lx, 2) if lx else None, np.polyfit(ry, rx, 2) if rx else None]
+            got = sm.update(lines)
+        for side in range(2):
+            if cur[side] is not None:
+                prev[side] = cur[side] if prev[side] is None else prev[side] * 0.9 + cur[side] * 0.1
+            assert (got[side] is None) == (prev[side] is None)
+            if prev[side] is not None:
+                assert np.array_equal(got[side], prev[side])
