@@ -6,7 +6,8 @@
  * (opencv-python, unpinned by the reference, absent from /root/reference and
  * from this image).  Contract restated: OpenCV >= 4.5.2 generic (non-IPP,
  * no-FMA) code path of modules/imgproc {color_rgb.simd.hpp, smooth.simd.hpp,
- * canny.cpp, drawing.cpp, hough.cpp} and modules/core {arithm.cpp, rng}.
+ * canny.cpp, drawing.cpp, hough.cpp, color_hsv.simd.hpp} and modules/core
+ * {arithm.cpp, rng}.
  *
  * PARITY UNPINNED: the reference holds no tests, golden vectors or sample
  * inputs for this path and no cv2 can be imported here, so this file is
@@ -25,6 +26,7 @@
  *   fillPoly      ..._2(images).py:14-20, F1_vo_Lane_Tracking.py:105-111,158-175
  *   rectangle     F1_vo_Lane_Tracking.py:179-180 (filled)
  *   bitwise_and   ..._2(images).py:23, F1_vo_Lane_Tracking.py:102 (mask=), :112
+ *   BGR2HSV, inRange, bitwise_or, bitwise_and(mask=)  ..._6(mp4).py:65-88
  *   HoughLinesP   ..._2(images).py:84-92 (6, pi/60, 160, 40, 25),
  *                 ..._5(mp4).py:76-84    (6, pi/60, 130, 40, 150)
  *
@@ -721,6 +723,127 @@ done:
 }
 
 /* ------------------------------------------------------------------ */
+/* Colour gate of the HSV-gated lane scripts                           */
+/* (Simple Lane Detection with OpenCV_6(mp4).py:65-88):                 */
+/*   cvtColor(BGR2HSV) -> inRange x2 -> bitwise_or ->                   */
+/*   bitwise_and(image, image, mask=) -> cvtColor(BGR2GRAY)             */
+/*                                                                      */
+/* cvtColor -> HSV, 8U, hue range 180: color_hsv.simd.hpp RGB2HSV_b.    */
+/* Fixed point with hsv_shift = 12 and two reciprocal tables            */
+/*   sdiv[i] = cvRound((255 << 12) / (double)i),                        */
+/*   hdiv[i] = cvRound((180 << 12) / (6. * i)),   sdiv[0] = hdiv[0] = 0 */
+/*   v = max(b,g,r), diff = v - min(b,g,r)                              */
+/*   s = (diff * sdiv[v] + 2^11) >> 12                                  */
+/*   h = v==r ? g-b : v==g ? b-r+2diff : r-g+4diff                      */
+/*   h = (h * hdiv[diff] + 2^11) >> 12;  h += 180 if h < 0              */
+/* ------------------------------------------------------------------ */
+#define LO_COLOR_BGR2HSV 40
+#define LO_COLOR_RGB2HSV 41
+
+static int lo_sdiv[256], lo_hdiv180[256], lo_hsv_ready;
+static void lo_hsv_tables(void)
+{
+    if (lo_hsv_ready) return;
+    lo_sdiv[0] = lo_hdiv180[0] = 0;
+    for (int i = 1; i < 256; i++) {
+        lo_sdiv[i] = cv_round_d((255 << 12) / (1. * i));
+        lo_hdiv180[i] = cv_round_d((180 << 12) / (6. * i));
+    }
+    lo_hsv_ready = 1;
+}
+
+static void lo_hsv_px(int b, int g, int r, int *ho, int *so, int *vo)
+{
+    int v = b, vmin = b;
+    if (g > v) v = g;
+    if (r > v) v = r;
+    if (g < vmin) vmin = g;
+    if (r < vmin) vmin = r;
+    const int diff = v - vmin;
+    const int s = (diff * lo_sdiv[v] + (1 << 11)) >> 12;
+    int h = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+    h = (h * lo_hdiv180[diff] + (1 << 11)) >> 12;      /* arithmetic shift of a negative h, as in C++ */
+    if (h < 0) h += 180;
+    *ho = h > 255 ? 255 : h; *so = s; *vo = v;
+}
+
+int lo_cvt_hsv(const uint8_t *src, int w, int h, long sstride, int code,
+               uint8_t *dst, long dstride)
+{
+    if (!src || !dst || w <= 0 || h <= 0) return LO_EINVAL;
+    if (code != LO_COLOR_BGR2HSV && code != LO_COLOR_RGB2HSV) return LO_EINVAL;
+    lo_hsv_tables();
+    const int bi = code == LO_COLOR_BGR2HSV ? 0 : 2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *p = src + y * sstride + 3 * x;
+            int hh, ss, vv;
+            lo_hsv_px(p[bi], p[1], p[bi ^ 2], &hh, &ss, &vv);
+            uint8_t *q = dst + y * dstride + 3 * x;
+            q[0] = (uint8_t)hh; q[1] = (uint8_t)ss; q[2] = (uint8_t)vv;
+        }
+    return LO_OK;
+}
+
+/* cv::inRange on 8UC3 with per-channel integer bounds (arithm.cpp):   */
+/* 255 where lo[c] <= src[c] <= hi[c] for all three channels, else 0.  */
+int lo_in_range3(const uint8_t *src, int w, int h, long sstride,
+                 const int *lo, const int *hi, uint8_t *dst, long dstride)
+{
+    if (!src || !dst || !lo || !hi || w <= 0 || h <= 0) return LO_EINVAL;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *p = src + y * sstride + 3 * x;
+            int ok = 1;
+            for (int c = 0; c < 3; c++) ok &= (p[c] >= lo[c] && p[c] <= hi[c]);
+            dst[y * dstride + x] = ok ? 255 : 0;
+        }
+    return LO_OK;
+}
+
+int lo_or(const uint8_t *a, long astride, const uint8_t *b, long bstride,
+          uint8_t *dst, long dstride, int w, int h)
+{
+    if (!a || !b || !dst || w <= 0 || h <= 0) return LO_EINVAL;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) dst[y * dstride + x] = a[y * astride + x] | b[y * bstride + x];
+    return LO_OK;
+}
+
+/* bitwise_and(src, src, mask=mask) on 8UC3 into a fresh (zero) dst.    */
+int lo_and3_mask(const uint8_t *src, long sstride, const uint8_t *mask, long mstride,
+                 uint8_t *dst, long dstride, int w, int h)
+{
+    if (!src || !mask || !dst || w <= 0 || h <= 0) return LO_EINVAL;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < 3; c++)
+                dst[y * dstride + 3 * x + c] = mask[y * mstride + x] ? src[y * sstride + 3 * x + c] : 0;
+    return LO_OK;
+}
+
+/* The whole gate, call by call: gate = lo0[3], hi0[3], lo1[3], hi1[3] in  */
+/* H, S, V order; gray_out = BGR2GRAY of the masked image.                */
+int lo_gate_gray(const uint8_t *bgr, int w, int h, const int *gate, int gray_code, uint8_t *gray_out)
+{
+    if (!bgr || !gate || !gray_out || w <= 0 || h <= 0) return LO_EINVAL;
+    size_t n = (size_t)w * h;
+    uint8_t *hsv = (uint8_t *)malloc(3 * n), *m0 = (uint8_t *)malloc(n), *m1 = (uint8_t *)malloc(n);
+    uint8_t *mk = (uint8_t *)malloc(3 * n);
+    int rc = LO_ENOMEM;
+    if (!hsv || !m0 || !m1 || !mk) goto done;
+    if ((rc = lo_cvt_hsv(bgr, w, h, 3L * w, LO_COLOR_BGR2HSV, hsv, 3L * w))) goto done;
+    if ((rc = lo_in_range3(hsv, w, h, 3L * w, gate, gate + 3, m0, w))) goto done;
+    if ((rc = lo_in_range3(hsv, w, h, 3L * w, gate + 6, gate + 9, m1, w))) goto done;
+    if ((rc = lo_or(m0, w, m1, w, m0, w, w, h))) goto done;
+    if ((rc = lo_and3_mask(bgr, 3L * w, m0, w, mk, 3L * w, w, h))) goto done;
+    rc = lo_cvt_gray(mk, w, h, 3L * w, gray_code, gray_out, w);
+done:
+    free(hsv); free(m0); free(m1); free(mk);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
 /* One frame through a recipe (the reference's call sequence), for the  */
 /* parity tests and the CPU baseline timing.                           */
 /*   code      LO_COLOR_*                                              */
@@ -729,18 +852,36 @@ done:
 /*   car_mask  w*h mask applied first as bitwise_and(e,e,mask=), or NULL */
 /* Outputs (each optional): gray, blurred, edges (pre-ROI), masked.     */
 /* ------------------------------------------------------------------ */
+int lo_lane_frame_gated(const uint8_t *bgr, int w, int h, int code, const int *gate, int blur,
+                        double t1, double t2, const uint8_t *car_mask, const uint8_t *roi,
+                        double rho, double theta, int threshold, double min_len, double max_gap,
+                        uint8_t *gray_out, uint8_t *blur_out, uint8_t *edges_out, uint8_t *masked_out,
+                        int32_t *acc_out, int acc_cap, int32_t *seg_out, int seg_cap, int *nseg_out);
+
 int lo_lane_frame(const uint8_t *bgr, int w, int h, int code, int blur,
                   double t1, double t2, const uint8_t *car_mask, const uint8_t *roi,
                   double rho, double theta, int threshold, double min_len, double max_gap,
                   uint8_t *gray_out, uint8_t *blur_out, uint8_t *edges_out, uint8_t *masked_out,
                   int32_t *acc_out, int acc_cap, int32_t *seg_out, int seg_cap, int *nseg_out)
 {
+    return lo_lane_frame_gated(bgr, w, h, code, 0, blur, t1, t2, car_mask, roi, rho, theta, threshold, min_len, max_gap,
+                               gray_out, blur_out, edges_out, masked_out, acc_out, acc_cap, seg_out, seg_cap, nseg_out);
+}
+
+/* gate: NULL, or the 12 bounds of lo_gate_gray (the colour gate in front of the gray conversion) */
+int lo_lane_frame_gated(const uint8_t *bgr, int w, int h, int code, const int *gate, int blur,
+                        double t1, double t2, const uint8_t *car_mask, const uint8_t *roi,
+                        double rho, double theta, int threshold, double min_len, double max_gap,
+                        uint8_t *gray_out, uint8_t *blur_out, uint8_t *edges_out, uint8_t *masked_out,
+                        int32_t *acc_out, int acc_cap, int32_t *seg_out, int seg_cap, int *nseg_out)
+{
     size_t n = (size_t)w * h;
     uint8_t *gray = (uint8_t *)malloc(n), *bl = (uint8_t *)malloc(n);
     uint8_t *ed = (uint8_t *)malloc(n), *mk = (uint8_t *)malloc(n);
     int rc = LO_ENOMEM;
     if (!gray || !bl || !ed || !mk) goto done;
-    if ((rc = lo_cvt_gray(bgr, w, h, 3L * w, code, gray, w))) goto done;
+    if (gate) { if ((rc = lo_gate_gray(bgr, w, h, gate, code, gray))) goto done; }
+    else if ((rc = lo_cvt_gray(bgr, w, h, 3L * w, code, gray, w))) goto done;
     if (blur) { if ((rc = lo_gaussian5(gray, w, h, w, bl, w))) goto done; }
     else memcpy(bl, gray, n);
     if ((rc = lo_canny(bl, w, h, w, t1, t2, ed, w, 0))) goto done;

@@ -16,6 +16,8 @@ _SO = os.path.join(_HERE, "liblane_oracle.so")
 
 COLOR_BGR2GRAY = 6
 COLOR_RGB2GRAY = 7
+COLOR_BGR2HSV = 40
+COLOR_RGB2HSV = 41
 
 
 class OracleError(Exception):
@@ -103,6 +105,58 @@ def bitwise_and(a, b, mask=None):
     return out
 
 
+def _i3(v):
+    a = np.ascontiguousarray(np.rint(np.asarray(v, dtype=np.float64)).astype(np.int32).reshape(-1))
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def cvt_hsv(bgr, code=COLOR_BGR2HSV):
+    bgr, p = _u8(bgr)
+    h, w, _ = bgr.shape
+    out = np.empty((h, w, 3), np.uint8)
+    _chk(lib().lo_cvt_hsv(p, w, h, C.c_long(3 * w), code, out.ctypes.data_as(C.c_void_p), C.c_long(3 * w)), "cvt_hsv")
+    return out
+
+
+def in_range(img3, lower, upper):
+    img3, p = _u8(img3)
+    h, w, _ = img3.shape
+    lo, plo = _i3(lower)
+    hi, phi = _i3(upper)
+    out = np.empty((h, w), np.uint8)
+    _chk(lib().lo_in_range3(p, w, h, C.c_long(3 * w), plo, phi, out.ctypes.data_as(C.c_void_p), C.c_long(w)), "in_range")
+    return out
+
+
+def bitwise_or(a, b):
+    a, pa = _u8(a)
+    b, pb = _u8(b)
+    h, w = a.shape
+    out = np.empty((h, w), np.uint8)
+    _chk(lib().lo_or(pa, C.c_long(w), pb, C.c_long(w), out.ctypes.data_as(C.c_void_p), C.c_long(w), w, h), "or")
+    return out
+
+
+def and3_mask(img3, mask):
+    """bitwise_and(img3, img3, mask=mask) into a fresh image."""
+    img3, p = _u8(img3)
+    mask, pm = _u8(mask)
+    h, w, _ = img3.shape
+    out = np.empty((h, w, 3), np.uint8)
+    _chk(lib().lo_and3_mask(p, C.c_long(3 * w), pm, C.c_long(w), out.ctypes.data_as(C.c_void_p), C.c_long(3 * w), w, h), "and3_mask")
+    return out
+
+
+def gate_gray(bgr, gate, gray_code=COLOR_BGR2GRAY):
+    """gate: ((lo0, hi0), (lo1, hi1)), each bound three H, S, V integers."""
+    bgr, p = _u8(bgr)
+    h, w, _ = bgr.shape
+    g, pg = _i3(gate)
+    out = np.empty((h, w), np.uint8)
+    _chk(lib().lo_gate_gray(p, w, h, pg, gray_code, out.ctypes.data_as(C.c_void_p)), "gate_gray")
+    return out
+
+
 def fill_poly(img, contours, color):
     """In place, like cv2.fillPoly.  contours: list of (N,2) integer arrays."""
     assert img.dtype == np.uint8 and img.ndim == 2 and img.flags.c_contiguous
@@ -169,7 +223,7 @@ def hough_lines_p(img, rho, theta, threshold, min_line_length=0, max_line_gap=0,
 
 
 def lane_frame(bgr, code, blur, t1, t2, roi, rho, theta, threshold, min_len, max_gap,
-               car_mask=None, seg_cap=4096, want_acc=True, want_segments=True):
+               car_mask=None, seg_cap=4096, want_acc=True, want_segments=True, gate=None):
     """One frame through a recipe.  Returns a dict of every intermediate."""
     bgr, p = _u8(bgr)
     h, w, _ = bgr.shape
@@ -184,7 +238,8 @@ def lane_frame(bgr, code, blur, t1, t2, roi, rho, theta, threshold, min_len, max
     roi_p = _u8(roi) if roi is not None else (None, None)
     car_p = _u8(car_mask) if car_mask is not None else (None, None)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    _chk(lib().lo_lane_frame(p, w, h, code, int(bool(blur)), C.c_double(t1), C.c_double(t2),
+    gate_p = _i3(gate) if gate is not None else (None, None)
+    _chk(lib().lo_lane_frame_gated(p, w, h, code, gate_p[1], int(bool(blur)), C.c_double(t1), C.c_double(t2),
                              car_p[1], roi_p[1], C.c_double(rho), C.c_double(theta), int(threshold),
                              C.c_double(min_len), C.c_double(max_gap),
                              vp(g), vp(b), vp(e), vp(m),
