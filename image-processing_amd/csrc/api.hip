@@ -199,6 +199,8 @@ struct lc_ctx {
     Work work;            // batch-1 working set of the per-op calls, keyed by (w, h)
     int work_w = 0, work_h = 0;
     DevBuf<uint8_t> tmpA, tmpB, tmpC, tmpD;
+    DevBuf<uint8_t> tmp3;     // a 3-channel image of the current size (colour gate per-op calls)
+    DevBuf<int> hsv_tab;      // sdiv[256], hdiv[256] of the 8-bit HSV conversion
 };
 
 namespace {
@@ -228,6 +230,21 @@ int ctx_work(lc_ctx *ctx, int w, int h) {
     if ((rc = ctx->tmpA.alloc(n)) || (rc = ctx->tmpB.alloc(n)) || (rc = ctx->tmpC.alloc(n)) || (rc = ctx->tmpD.alloc(n))) return rc;
     ctx->work_w = w; ctx->work_h = h;
     return LC_OK;
+}
+
+int ctx_hsv_tab(lc_ctx *ctx) {
+    if (ctx->hsv_tab.p) return LC_OK;
+    int rc, tab[512];
+    hsv_tables_host(tab);
+    if ((rc = ctx->hsv_tab.alloc(512))) return rc;
+    HIP_TRY(hipMemcpy(ctx->hsv_tab.p, tab, sizeof tab, hipMemcpyHostToDevice));
+    return LC_OK;
+}
+
+int ctx_tmp3(lc_ctx *ctx, int w, int h) {
+    const size_t n = 3 * (size_t)w * h;
+    if (ctx->tmp3.n >= n) return LC_OK;
+    return ctx->tmp3.alloc(n);
 }
 
 int up2d(void *dst, const void *src, size_t row_bytes, int h, size_t stride, hipStream_t st) {
@@ -373,6 +390,61 @@ int lc_cvt_gray(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride
     if ((rc = up2d(ctx->work.bgr.p, src, 3 * (size_t)w, h, src_stride, ctx->stream))) return rc;
     launch_gray(ctx->work.bgr.p, w, h, 1, code, ctx->tmpA.p, ctx->stream);
     return down2d(dst, dst_stride, ctx->tmpA.p, w, h, ctx->stream);
+}
+
+int lc_cvt_hsv(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, int code, uint8_t *dst, size_t dst_stride) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if (code != LC_COLOR_BGR2HSV && code != LC_COLOR_RGB2HSV)
+        return fail(LC_EUNSUPPORTED, "cvtColor: only COLOR_BGR2HSV (40) and COLOR_RGB2HSV (41) are supported here, got %d", code);
+    if ((rc = check_image(src, w, h, src_stride, 3 * (size_t)w, "cvtColor src"))) return rc;
+    if ((rc = check_image(dst, w, h, dst_stride, 3 * (size_t)w, "cvtColor dst"))) return rc;
+    if ((rc = ctx_work(ctx, w, h)) || (rc = ctx_tmp3(ctx, w, h)) || (rc = ctx_hsv_tab(ctx))) return rc;
+    if ((rc = up2d(ctx->work.bgr.p, src, 3 * (size_t)w, h, src_stride, ctx->stream))) return rc;
+    launch_hsv(ctx->work.bgr.p, (size_t)w * h, code, ctx->hsv_tab.p, ctx->tmp3.p, ctx->stream);
+    return down2d(dst, dst_stride, ctx->tmp3.p, 3 * (size_t)w, h, ctx->stream);
+}
+
+int lc_in_range3(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, const int *lowerb, const int *upperb,
+                 uint8_t *dst, size_t dst_stride) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if (!lowerb || !upperb) return fail(LC_EINVAL, "inRange: null bounds");
+    if ((rc = check_image(src, w, h, src_stride, 3 * (size_t)w, "inRange src"))) return rc;
+    if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "inRange dst"))) return rc;
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    if ((rc = up2d(ctx->work.bgr.p, src, 3 * (size_t)w, h, src_stride, ctx->stream))) return rc;
+    const int b[6] = {lowerb[0], lowerb[1], lowerb[2], upperb[0], upperb[1], upperb[2]};
+    launch_in_range3(ctx->work.bgr.p, (size_t)w * h, make_gate(b, 1), ctx->tmpA.p, ctx->stream);
+    return down2d(dst, dst_stride, ctx->tmpA.p, w, h, ctx->stream);
+}
+
+int lc_or(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size_t b_stride, uint8_t *dst, size_t dst_stride,
+          int w, int h) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(a, w, h, a_stride, (size_t)w, "bitwise_or src1"))) return rc;
+    if ((rc = check_image(b, w, h, b_stride, (size_t)w, "bitwise_or src2"))) return rc;
+    if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "bitwise_or dst"))) return rc;
+    if ((rc = ctx_work(ctx, w, h))) return rc;
+    if ((rc = up2d(ctx->tmpA.p, a, w, h, a_stride, ctx->stream))) return rc;
+    if ((rc = up2d(ctx->tmpB.p, b, w, h, b_stride, ctx->stream))) return rc;
+    launch_or(ctx->tmpA.p, ctx->tmpB.p, ctx->tmpD.p, (size_t)w * h, ctx->stream);
+    return down2d(dst, dst_stride, ctx->tmpD.p, w, h, ctx->stream);
+}
+
+int lc_and3_mask(lc_ctx *ctx, const uint8_t *src, size_t src_stride, const uint8_t *mask, size_t mask_stride, uint8_t *dst,
+                 size_t dst_stride, int w, int h) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = check_image(src, w, h, src_stride, 3 * (size_t)w, "bitwise_and src"))) return rc;
+    if ((rc = check_image(mask, w, h, mask_stride, (size_t)w, "bitwise_and mask"))) return rc;
+    if ((rc = check_image(dst, w, h, dst_stride, 3 * (size_t)w, "bitwise_and dst"))) return rc;
+    if ((rc = ctx_work(ctx, w, h)) || (rc = ctx_tmp3(ctx, w, h))) return rc;
+    if ((rc = up2d(ctx->work.bgr.p, src, 3 * (size_t)w, h, src_stride, ctx->stream))) return rc;
+    if ((rc = up2d(ctx->tmpC.p, mask, w, h, mask_stride, ctx->stream))) return rc;
+    launch_and3_mask(ctx->work.bgr.p, ctx->tmpC.p, ctx->tmp3.p, (size_t)w * h, ctx->stream);
+    return down2d(dst, dst_stride, ctx->tmp3.p, 3 * (size_t)w, h, ctx->stream);
 }
 
 int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, uint8_t *dst, size_t dst_stride) {
@@ -606,6 +678,8 @@ struct lc_pipe {
     int low = 0, high = 0, line_length = 0, line_gap = 0;
     DevBuf<uint64_t> roi_bits;
     bool has_roi = false;
+    bool has_gate = false;        // colour gate in front of the gray conversion
+    GateDev gate{};
     // A pipeline owns three streams, whatever its number of slots; a slot is a set of buffers and events.
     // (HIP maps streams onto a few hardware queues.  Streams that share one see each other's event waits as
     // barriers, which at best serialises batches that should overlap and at worst ties two queues into a
@@ -715,7 +789,8 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     }
     HIP_TRY(hipEventRecord(s.ev[EV_ESTART], es));
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
-                 w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es);
+                 w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
+                 pp->has_gate ? &pp->gate : nullptr, pp->ctx->hsv_tab.p, w.gray.p);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
     launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, es);
@@ -767,6 +842,12 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     pp->line_length = (int)lrint(p.min_line_length);
     pp->line_gap = (int)lrint(p.max_line_gap);
 
+    if (p.hsv_gate) {
+        if ((rc = ctx_hsv_tab(ctx))) { delete pp; return rc; }
+        pp->has_gate = true;
+        pp->gate = make_gate(p.hsv_bounds, 2);
+    }
+
     // ROI and car mask fold into one bit plane: keep = (roi == 255) && (car != 0)
     if (p.roi_mask || p.car_mask) {
         const Geo g = pp->g;
@@ -814,6 +895,9 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
         }
         if ((rc = s.w.init_images(p.width, p.height, p.max_batch, true, p.keep_intermediates != 0, true))) { lc_pipe_destroy(pp); return rc; }
+        // frames the streaming front kernel cannot take pass through a gated gray image
+        if (pp->has_gate && !s.w.gray.p && !front_stream_supported(pp->g) &&
+            (rc = s.w.gray.alloc((size_t)p.max_batch * p.width * p.height))) { lc_pipe_destroy(pp); return rc; }
         if (hough) {
             // point list capacity per frame: an eighth of the pixels (a Canny map inside an ROI stays far below)
             int cap = std::max(1024, (int)std::min<size_t>((size_t)p.width * p.height, (size_t)p.width * p.height / 8 + 1024));

@@ -36,19 +36,41 @@ struct AngleEntry {
     int pad;
 };
 
+// Colour gate in front of the gray conversion: a pixel is kept when its 8-bit HSV value (hue range 180)
+// lies in either of two boxes.  A channel test is (x - lo) <= span on unsigned numbers; an empty range
+// has lo = 1000, span = 0.  Box 0 takes lo[0..2] / span[0..2] in H, S, V order, box 1 the rest.
+struct GateDev { int lo[6]; uint32_t span[6]; };
+// bounds: lo0[3], hi0[3], lo1[3], hi1[3] as the inRange calls receive them (any integers);
+// nboxes = 1 leaves the second box empty
+GateDev make_gate(const int *bounds, int nboxes);
+// the two reciprocal tables of the HSV conversion, sdiv[256] then hdiv[256]
+void hsv_tables_host(int *tab512);
+
 // ---- launchers (each enqueues on `st`; no synchronisation inside) ----------
+// colour gate (kernels_gate.hip); tab = device copy of hsv_tables_host
+void launch_hsv(const uint8_t *src, size_t npix, int code, const int *tab, uint8_t *dst, hipStream_t st);
+void launch_in_range3(const uint8_t *src, size_t npix, GateDev box0, uint8_t *dst, hipStream_t st);
+void launch_or(const uint8_t *a, const uint8_t *b, uint8_t *dst, size_t n, hipStream_t st);
+void launch_and3_mask(const uint8_t *src, const uint8_t *mask, uint8_t *dst, size_t npix, hipStream_t st);
+void launch_gate_gray(const uint8_t *bgr, size_t npix, int gray_code, const int *tab, GateDev gate, uint8_t *gray,
+                      hipStream_t st);
 // edge stage
 void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_t *gray, hipStream_t st);
 // streaming front kernel (kernels_front_stream.hip): interleaved 3-channel input, W % 4 == 0
 bool front_stream_supported(Geo g);
+// gate (may be null): the colour gate applied to the frame before the gray conversion; tab as above
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, int rows_per_unit,
-                         hipStream_t st);
+                         const GateDev *gate, const int *tab, hipStream_t st);
 void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st);
 // in_kind: 0 = gray bytes in, 1 = interleaved 3-channel bytes in
+// gate (may be null, 3-channel input only): colour gate in front of the gray conversion.  Frames the
+// streaming kernel cannot take go through a gated gray image first: gate_gray (nframes * W * H bytes)
+// is where it is put, and it may be the same buffer as gray_out.
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes,
                   int low, int high, uint64_t *planeS, uint64_t *planeW,
-                  uint8_t *gray_out, uint8_t *blur_out, hipStream_t st);
+                  uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
+                  const GateDev *gate = nullptr, const int *tab = nullptr, uint8_t *gate_gray = nullptr);
 // hysteresis to the fixed point: a chip-wide first round, then one workgroup per frame closes
 // the chains that cross tile borders; rounds[f] receives the closure rounds frame f needed
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,

@@ -1,0 +1,38 @@
+// Device side of the colour gate (8-bit HSV conversion and range tests), shared by the per-op kernels
+// and the front kernels that fuse the gate into the gray conversion.
+#pragma once
+#include "common.h"
+
+namespace lanecv {
+
+// OpenCV's 8U RGB2HSV (hue range 180) in fixed point, hsv_shift = 12:
+//   v = max(b,g,r), diff = v - min(b,g,r), s = (diff * sdiv[v] + 2^11) >> 12,
+//   h = v==r ? g-b : v==g ? b-r+2diff : r-g+4diff;  h = (h * hdiv[diff] + 2^11) >> 12;  h += 180 if h < 0
+// tab: sdiv[256] followed by hdiv[256] (global or LDS)
+__device__ __forceinline__ void hsv_px(int b, int g, int r, const int *tab, int &h, int &s, int &v) {
+    v = max(b, max(g, r));
+    const int diff = v - min(b, min(g, r));
+    const int sd = tab[v], hd = tab[256 + diff];
+    s = (diff * sd + (1 << 11)) >> 12;
+    const int hh = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+    h = (hh * hd + (1 << 11)) >> 12;
+    h += h < 0 ? 180 : 0;
+}
+
+// true when (h, s, v) lies inside either of the gate's two boxes
+__device__ __forceinline__ bool gate_pass(int h, int s, int v, const GateDev &gt) {
+    const bool in0 = (uint32_t)(h - gt.lo[0]) <= gt.span[0] && (uint32_t)(s - gt.lo[1]) <= gt.span[1] &&
+                     (uint32_t)(v - gt.lo[2]) <= gt.span[2];
+    const bool in1 = (uint32_t)(h - gt.lo[3]) <= gt.span[3] && (uint32_t)(s - gt.lo[4]) <= gt.span[4] &&
+                     (uint32_t)(v - gt.lo[5]) <= gt.span[5];
+    return in0 || in1;
+}
+
+// p = B | G << 8 | R << 16 (bits 24-31 ignored): does the gate keep the pixel?
+__device__ __forceinline__ bool gate_keep(uint32_t p, const int *tab, const GateDev &gt) {
+    int h, s, v;
+    hsv_px((int)(p & 255u), (int)((p >> 8) & 255u), (int)((p >> 16) & 255u), tab, h, s, v);
+    return gate_pass(h, s, v, gt);
+}
+
+}  // namespace lanecv

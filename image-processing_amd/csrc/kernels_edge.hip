@@ -529,13 +529,20 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 }
 
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes, int low,
-                  int high, uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, hipStream_t st) {
+                  int high, uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
+                  const GateDev *gate, const int *tab, uint8_t *gate_gray) {
     static const char *force_tiled = getenv("LANECV_FRONT_TILED");       // diagnostics: use the tiled kernel everywhere
     static const char *rows_env = getenv("LANECV_FRONT_ROWS");           // tuning: rows per streaming unit
     if (in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1')) {
         launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, gray_out, blur_out,
-                            rows_env ? atoi(rows_env) : 0, st);
+                            rows_env ? atoi(rows_env) : 0, gate, tab, st);
         return;
+    }
+    if (gate && in_kind == 1) {   // gated gray first, then the tiled kernel on that gray image
+        const size_t npix = (size_t)g.W * g.H * nframes;
+        launch_gate_gray(src, npix, code, tab, *gate, gate_gray, st);
+        src = gate_gray; src_bytes = npix; in_kind = 0;
+        if (gray_out == gate_gray) gray_out = nullptr;   // already there
     }
     int k0 = code == 6 ? 3735 : 9798, k2 = code == 6 ? 9798 : 3735;
     dim3 grid(g.TX, (g.H + FT_H - 1) / FT_H, nframes), block(FNT);

@@ -27,7 +27,7 @@
 //   borders: gray reflects (101) for the blur, the Sobel input replicates, magnitudes outside the image are 0
 // Requires W % 4 == 0 (lanes are then wholly inside or wholly outside the image); other widths and
 // gray input take the tiled kernel in kernels_edge.hip.
-#include "common.h"
+#include "gate.h"
 #include <type_traits>
 
 namespace lanecv {
@@ -106,6 +106,8 @@ struct FrontArgs {
     uint64_t *planeS, *planeW;
     uint8_t *gray_out, *blur_out;
     int rows_per_unit, nseg, nstrips, nunits;
+    const int *gate_tab;     // GATE only: the HSV reciprocal tables in device memory
+    GateDev gate;
 };
 
 struct Pair { uint32_t e, o; };   // 4 packed 16-bit values of a lane: e = (px0, px2), o = (px1, px3)
@@ -114,8 +116,16 @@ constexpr int STRIP = 248;        // output columns of a wavefront
 
 template <int P> using Phase = std::integral_constant<int, P>;
 
-template <bool BLUR>
+// GATE: the colour gate of the HSV-gated script in front of the gray conversion -- a pixel outside both
+// HSV boxes counts as black, so its gray value is 0.  The two 256-entry reciprocal tables sit in LDS (2 KiB
+// a workgroup; LDS reads have their own wait counter, so they do not disturb the grouped memory traffic).
+template <bool BLUR, bool GATE>
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
+    __shared__ int gtab[GATE ? 512 : 1];
+    if constexpr (GATE) {
+        for (int i = threadIdx.x; i < 512; i += 256) gtab[i] = a.gate_tab[i];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int u = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform
     if (u >= a.nunits) return;
@@ -185,6 +195,11 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         const uint32_t t2 = (dot4(p2, a.k_hi, 0) << 8) + dot4(p2, a.k_lo, 1u << 15);
         const uint32_t t3 = (dot4(p3, a.k_hi, 0) << 8) + dot4(p3, a.k_lo, 1u << 15);
         uint32_t G = __builtin_amdgcn_perm(t1, t0, 0x0c0c0602u) | __builtin_amdgcn_perm(t3, t2, 0x06020c0cu);
+        if constexpr (GATE) {
+            const uint32_t km = (gate_keep(p0, gtab, a.gate) ? 0x000000FFu : 0u) | (gate_keep(p1, gtab, a.gate) ? 0x0000FF00u : 0u) |
+                                (gate_keep(p2, gtab, a.gate) ? 0x00FF0000u : 0u) | (gate_keep(p3, gtab, a.gate) ? 0xFF000000u : 0u);
+            G &= km;
+        }
         if (a.gray_out && v >= y0 && v < y1) {
             if (inimg && emits) *reinterpret_cast<uint32_t *>(a.gray_out + (size_t)f * W * H + (size_t)v * W + px) = G;
         }
@@ -311,8 +326,10 @@ bool front_stream_supported(Geo g) { return g.W % 4 == 0 && g.W >= 8; }
 
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, int rows_per_unit,
-                         hipStream_t st) {
+                         const GateDev *gate, const int *tab, hipStream_t st) {
     FrontArgs a;
+    a.gate_tab = tab;
+    if (gate) a.gate = *gate; else a.gate = GateDev{};
     a.src = src; a.g = g; a.low = low; a.high = high;
     a.planeS = planeS; a.planeW = planeW; a.gray_out = gray_out; a.blur_out = blur_out;
     // twice the 15-bit weights, so that the gray value lands on a byte boundary of the sum
@@ -332,8 +349,13 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.nseg = (g.H + rows_per_unit - 1) / rows_per_unit;
     a.nunits = nframes * a.nseg * a.nstrips;
     dim3 grid((a.nunits + 3) / 4), block(256);
-    if (blur) hipLaunchKernelGGL(k_front_stream<true>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(k_front_stream<false>, grid, block, 0, st, a);
+    if (gate) {
+        if (blur) hipLaunchKernelGGL((k_front_stream<true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_front_stream<false, true>), grid, block, 0, st, a);
+    } else {
+        if (blur) hipLaunchKernelGGL((k_front_stream<true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_front_stream<false, false>), grid, block, 0, st, a);
+    }
 }
 
 }  // namespace lanecv

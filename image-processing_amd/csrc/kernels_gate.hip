@@ -1,0 +1,120 @@
+// Colour gate of the HSV-gated lane script: cvtColor(BGR2HSV), inRange, bitwise_or and the masked
+// bitwise_and as stand-alone kernels (the per-op entry points), and the gate folded into a gray
+// conversion (the pre-pass of frames the streaming front kernel cannot take).
+//
+// bitwise_and(image, image, mask=m) followed by BGR2GRAY equals "gray of the pixel where m is set,
+// else 0" (the gray of a black pixel is (2^14) >> 15 = 0), so the fused forms never build the masked
+// colour image.
+#include "gate.h"
+#include <cmath>
+
+namespace lanecv {
+namespace {
+
+__global__ __launch_bounds__(256) void k_hsv(const uint8_t *__restrict__ src, size_t npix, int swap_rb,
+                                             const int *__restrict__ tab, uint8_t *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint8_t *p = src + 3 * i;
+    int h, s, v;
+    hsv_px(p[swap_rb ? 2 : 0], p[1], p[swap_rb ? 0 : 2], tab, h, s, v);
+    uint8_t *q = dst + 3 * i;
+    q[0] = (uint8_t)h; q[1] = (uint8_t)s; q[2] = (uint8_t)v;
+}
+
+__global__ __launch_bounds__(256) void k_in_range3(const uint8_t *__restrict__ src, size_t npix, GateDev box,
+                                                   uint8_t *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint8_t *p = src + 3 * i;
+    dst[i] = gate_pass(p[0], p[1], p[2], box) ? 255 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_or(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                            uint8_t *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = a[i] | b[i];
+}
+
+__global__ __launch_bounds__(256) void k_and3_mask(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask,
+                                                   uint8_t *__restrict__ dst, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const bool keep = mask[i] != 0;
+    dst[3 * i] = keep ? src[3 * i] : 0;
+    dst[3 * i + 1] = keep ? src[3 * i + 1] : 0;
+    dst[3 * i + 2] = keep ? src[3 * i + 2] : 0;
+}
+
+// gated gray, 4 pixels (12 source bytes) per thread; the gate always reads the frame as B, G, R
+__global__ __launch_bounds__(256) void k_gate_gray(const uint8_t *__restrict__ src, size_t npix, int k0, int k1, int k2,
+                                                   const int *__restrict__ tab_g, GateDev gate,
+                                                   uint8_t *__restrict__ dst) {
+    __shared__ int tab[512];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) tab[i] = tab_g[i];
+    __syncthreads();
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t p0 = q * 4;
+    if (p0 >= npix) return;
+    auto one = [&](uint32_t px) -> uint32_t {   // px = c0 | c1 << 8 | c2 << 16
+        const uint32_t gy = ((px & 255) * k0 + ((px >> 8) & 255) * k1 + ((px >> 16) & 255) * k2 + (1 << 14)) >> 15;
+        return gate_keep(px, tab, gate) ? gy : 0u;
+    };
+    if (p0 + 4 <= npix) {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(src) + q * 3;
+        const uint32_t a = s[0], b = s[1], c = s[2];
+        const uint32_t g0 = one(a), g1 = one((a >> 24) | (b << 8)), g2 = one((b >> 16) | (c << 16)), g3 = one(c >> 8);
+        reinterpret_cast<uint32_t *>(dst)[q] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    } else {
+        for (size_t p = p0; p < npix; p++)
+            dst[p] = (uint8_t)one(src[3 * p] | ((uint32_t)src[3 * p + 1] << 8) | ((uint32_t)src[3 * p + 2] << 16));
+    }
+}
+
+unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+void hsv_tables_host(int *tab) {
+    tab[0] = tab[256] = 0;
+    for (int i = 1; i < 256; i++) {
+        tab[i] = (int)std::lrint((255 << 12) / (double)i);          // cvRound: to nearest, ties to even
+        tab[256 + i] = (int)std::lrint((180 << 12) / (6. * i));
+    }
+}
+
+GateDev make_gate(const int *b, int nboxes) {
+    GateDev g;
+    for (int box = 0; box < 2; box++)
+        for (int c = 0; c < 3; c++) {
+            int lo = 1000, hi = 1000;
+            if (box < nboxes) {
+                lo = b[6 * box + c] < 0 ? 0 : b[6 * box + c];
+                hi = b[6 * box + 3 + c] > 255 ? 255 : b[6 * box + 3 + c];
+                if (lo > hi) lo = hi = 1000;
+            }
+            g.lo[3 * box + c] = lo;
+            g.span[3 * box + c] = (uint32_t)(hi - lo);
+        }
+    return g;
+}
+
+void launch_hsv(const uint8_t *src, size_t npix, int code, const int *tab, uint8_t *dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_hsv, dim3(blocks_for(npix)), dim3(256), 0, st, src, npix, code == 41 ? 1 : 0, tab, dst);
+}
+void launch_in_range3(const uint8_t *src, size_t npix, GateDev box0, uint8_t *dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_in_range3, dim3(blocks_for(npix)), dim3(256), 0, st, src, npix, box0, dst);
+}
+void launch_or(const uint8_t *a, const uint8_t *b, uint8_t *dst, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_or, dim3(blocks_for(n)), dim3(256), 0, st, a, b, dst, n);
+}
+void launch_and3_mask(const uint8_t *src, const uint8_t *mask, uint8_t *dst, size_t npix, hipStream_t st) {
+    hipLaunchKernelGGL(k_and3_mask, dim3(blocks_for(npix)), dim3(256), 0, st, src, mask, dst, npix);
+}
+void launch_gate_gray(const uint8_t *bgr, size_t npix, int gray_code, const int *tab, GateDev gate, uint8_t *gray,
+                      hipStream_t st) {
+    const int k0 = gray_code == 6 ? 3735 : 9798, k2 = gray_code == 6 ? 9798 : 3735;
+    hipLaunchKernelGGL(k_gate_gray, dim3(blocks_for((npix + 3) / 4)), dim3(256), 0, st, bgr, npix, k0, 19235, k2, tab, gate, gray);
+}
+
+}  // namespace lanecv

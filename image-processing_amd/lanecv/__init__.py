@@ -4,9 +4,10 @@
 OpenCV_*.py` scripts and `LaneTracker.detect_and_draw` of `F1_vo_Lane_Tracking.py`
 source-compatible for these calls:
 
-    cvtColor (COLOR_BGR2GRAY / COLOR_RGB2GRAY), GaussianBlur ((5,5), sigma 0),
-    Canny (aperture 3, L1), fillPoly (LINE_8, shift 0), rectangle (filled),
-    bitwise_and (optional mask), HoughLinesP
+    cvtColor (COLOR_BGR2GRAY / COLOR_RGB2GRAY / COLOR_BGR2HSV / COLOR_RGB2HSV),
+    GaussianBlur ((5,5), sigma 0), Canny (aperture 3, L1), fillPoly (LINE_8, shift 0),
+    rectangle (filled), inRange (8UC3, integer bounds), bitwise_or, bitwise_and (optional mask),
+    HoughLinesP
 
 Same positional/keyword signatures and return conventions as cv2 (fillPoly and
 rectangle work in place and return the image; HoughLinesP returns an (N,1,4)
@@ -22,11 +23,13 @@ import numpy as _np
 from . import _abi
 from ._abi import error
 
-__all__ = ["cvtColor", "GaussianBlur", "Canny", "fillPoly", "rectangle", "bitwise_and", "HoughLinesP",
-           "hough_accumulator", "error"]
+__all__ = ["cvtColor", "GaussianBlur", "Canny", "fillPoly", "rectangle", "inRange", "bitwise_or", "bitwise_and",
+           "HoughLinesP", "hough_accumulator", "error"]
 
 COLOR_BGR2GRAY = 6
 COLOR_RGB2GRAY = 7
+COLOR_BGR2HSV = 40
+COLOR_RGB2HSV = 41
 BORDER_REPLICATE = 1
 BORDER_REFLECT_101 = 4
 BORDER_REFLECT101 = 4
@@ -69,17 +72,25 @@ def _dst(dst, shape):
 
 
 def cvtColor(src, code, dst=None, dstCn=0):
-    """cv2.cvtColor for COLOR_BGR2GRAY and COLOR_RGB2GRAY (8UC3 -> 8UC1).
-    Reference: Simple Lane Detection with OpenCV_2(images).py:69, F1_vo_Lane_Tracking.py:186."""
-    if code not in (COLOR_BGR2GRAY, COLOR_RGB2GRAY):
+    """cv2.cvtColor for COLOR_BGR2GRAY / COLOR_RGB2GRAY (8UC3 -> 8UC1) and COLOR_BGR2HSV / COLOR_RGB2HSV
+    (8UC3 -> 8UC3, hue in [0, 180)).
+    Reference: Simple Lane Detection with OpenCV_2(images).py:69, F1_vo_Lane_Tracking.py:186,
+    Simple Lane Detection with OpenCV_6(mp4).py:65."""
+    if code not in (COLOR_BGR2GRAY, COLOR_RGB2GRAY, COLOR_BGR2HSV, COLOR_RGB2HSV):
         raise error("cvtColor: unsupported conversion code %r" % (code,), _abi.LC_EUNSUPPORTED)
     src = _image(src, "src", 3)
     if src.shape[2] != 3:
         raise error("cvtColor: expected 3 channels, got %d" % src.shape[2], _abi.LC_EUNSUPPORTED)
-    if dstCn not in (0, 1):
-        raise error("cvtColor: dstCn must be 0 or 1 for a gray destination")
     s, stride = _rows(src)
     h, w = s.shape[:2]
+    if code in (COLOR_BGR2HSV, COLOR_RGB2HSV):
+        if dstCn not in (0, 3):
+            raise error("cvtColor: dstCn must be 0 or 3 for an HSV destination")
+        out = _dst(dst, (h, w, 3))
+        _abi.check(_abi.lib().lc_cvt_hsv(_abi.context(), _abi.ptr(s), w, h, stride, int(code), _abi.ptr(out), 3 * w))
+        return out
+    if dstCn not in (0, 1):
+        raise error("cvtColor: dstCn must be 0 or 1 for a gray destination")
     out = _dst(dst, (h, w))
     _abi.check(_abi.lib().lc_cvt_gray(_abi.context(), _abi.ptr(s), w, h, stride, int(code), _abi.ptr(out), w))
     return out
@@ -163,9 +174,80 @@ def rectangle(img, pt1, pt2, color, thickness=1, lineType=LINE_8, shift=0):
     return img
 
 
+def _bounds3(b, name):
+    a = _np.asarray(b)
+    if a.size != 3:
+        raise error("inRange: %s must hold three values for a 3-channel image, got shape %s" % (name, a.shape),
+                    _abi.LC_EUNSUPPORTED)
+    a = a.reshape(3)
+    if not _np.all(a == _np.floor(a)):
+        raise error("inRange: only integral bounds are supported", _abi.LC_EUNSUPPORTED)
+    return (_C.c_int * 3)(*[int(max(-1, min(256, v))) for v in a])
+
+
+def inRange(src, lowerb, upperb, dst=None):
+    """cv2.inRange on an 8UC3 image with three integral bounds per side: 255 where every channel lies in
+    [lowerb, upperb], else 0.  Reference: Simple Lane Detection with OpenCV_6(mp4).py:69-78."""
+    src = _image(src, "src", 3)
+    if src.shape[2] != 3:
+        raise error("inRange: expected 3 channels, got %d" % src.shape[2], _abi.LC_EUNSUPPORTED)
+    lo, hi = _bounds3(lowerb, "lowerb"), _bounds3(upperb, "upperb")
+    s, stride = _rows(src)
+    h, w = s.shape[:2]
+    out = _dst(dst, (h, w))
+    _abi.check(_abi.lib().lc_in_range3(_abi.context(), _abi.ptr(s), w, h, stride, lo, hi, _abi.ptr(out), w))
+    return out
+
+
+def bitwise_or(src1, src2, dst=None, mask=None):
+    """cv2.bitwise_or on 8UC1 images (no mask).  Reference: Simple Lane Detection with OpenCV_6(mp4).py:81."""
+    a = _image(src1, "src1", 2)
+    b = _image(src2, "src2", 2)
+    if a.shape != b.shape:
+        raise error("bitwise_or: sizes of the inputs differ: %s vs %s" % (a.shape, b.shape))
+    if mask is not None:
+        raise error("bitwise_or: a mask is not supported", _abi.LC_EUNSUPPORTED)
+    sa, ra = _rows(a)
+    sb, rb = _rows(b)
+    h, w = a.shape
+    out = _dst(dst, (h, w))
+    _abi.check(_abi.lib().lc_or(_abi.context(), _abi.ptr(sa), ra, _abi.ptr(sb), rb, _abi.ptr(out), w, w, h))
+    return out
+
+
+def _and3(src1, src2, dst, mask):
+    """bitwise_and on 8UC3 images: the channels are ANDed as one (h, 3w) plane, then the 8UC1 mask blacks out
+    whole pixels (`bitwise_and(image, image, mask=m)`, Simple Lane Detection with OpenCV_6(mp4).py:84)."""
+    a = _image(src1, "src1", 3)
+    b = _image(src2, "src2", 3)
+    if a.shape != b.shape or a.shape[2] != 3:
+        raise error("bitwise_and: expected two 3-channel images of one size, got %s and %s" % (a.shape, b.shape))
+    h, w = a.shape[:2]
+    a = _np.ascontiguousarray(a)
+    if src1 is src2:
+        both = a
+    else:
+        both = bitwise_and(a.reshape(h, 3 * w), _np.ascontiguousarray(b).reshape(h, 3 * w)).reshape(h, w, 3)
+    if mask is None:
+        if isinstance(dst, _np.ndarray) and dst.shape == both.shape and dst.dtype == _np.uint8:
+            dst[...] = both
+            return dst
+        return both.copy() if both is a else both
+    mask = _image(mask, "mask", 2)
+    if mask.shape != (h, w):
+        raise error("bitwise_and: mask size %s differs from the image size %s" % (mask.shape, (h, w)))
+    sm, rm = _rows(mask)
+    out = _dst(dst, (h, w, 3))
+    _abi.check(_abi.lib().lc_and3_mask(_abi.context(), _abi.ptr(both), 3 * w, _abi.ptr(sm), rm, _abi.ptr(out), 3 * w, w, h))
+    return out
+
+
 def bitwise_and(src1, src2, dst=None, mask=None):
-    """cv2.bitwise_and on 8UC1 images with an optional 8UC1 mask (dst is zero where mask is).
-    Reference: Simple Lane Detection with OpenCV_2(images).py:23, F1_vo_Lane_Tracking.py:102, :112."""
+    """cv2.bitwise_and on 8UC1 (or 8UC3) images with an optional 8UC1 mask (dst is zero where mask is).
+    Reference: Simple Lane Detection with OpenCV_2(images).py:23, F1_vo_Lane_Tracking.py:102, :112,
+    Simple Lane Detection with OpenCV_6(mp4).py:84 (3 channels)."""
+    if isinstance(src1, _np.ndarray) and src1.ndim == 3:
+        return _and3(src1, src2, dst, mask)
     a = _image(src1, "src1", 2)
     b = _image(src2, "src2", 2)
     if a.shape != b.shape:

@@ -64,6 +64,9 @@ class Recipe:
     max_line_gap: float = 25
     segments: bool = True
     accumulator: bool = False
+    # colour gate in front of the gray conversion: (lo0, hi0, lo1, hi1), each an (H, S, V) triple of the two
+    # inRange calls whose masks are ORed, or None
+    hsv_gate: Optional[tuple] = None
 
     @staticmethod
     def simple(w, h, threshold=160, max_line_gap=25):
@@ -75,6 +78,14 @@ class Recipe:
     def curve(w, h):
         """`Simple Lane Detection with OpenCV_5(mp4).py:66-84` (threshold 130, gap 150)."""
         return Recipe.simple(w, h, threshold=130, max_line_gap=150)
+
+    @staticmethod
+    def hsv_gated(w, h):
+        """`Simple Lane Detection with OpenCV_6(mp4).py:54-113`: white and yellow HSV boxes gate the frame,
+        BGR2GRAY, Canny(100,200), narrowed triangle, HoughLinesP(6, pi/60, 130, 40, 150)."""
+        return Recipe(color_code=6, blur=False, canny=(100, 200), roi_vertices=narrow_triangle_roi(w, h),
+                      threshold=130, max_line_gap=150,
+                      hsv_gate=((0, 0, 200), (180, 30, 255), (15, 100, 100), (35, 255, 255)))
 
     @staticmethod
     def f1(w, h):
@@ -114,6 +125,12 @@ class LanePipeline:
             min_line_length=float(recipe.min_line_length), max_line_gap=float(recipe.max_line_gap),
             seg_capacity=self.seg_capacity, want_accumulator=int(bool(recipe.accumulator)),
             want_segments=int(bool(recipe.segments)), keep_intermediates=int(self.keep))
+        if recipe.hsv_gate is not None:
+            flat = [int(v) for box in recipe.hsv_gate for v in box]
+            if len(flat) != 12:
+                raise error("hsv_gate: expected (lo0, hi0, lo1, hi1) with three values each")
+            p.hsv_gate = 1
+            p.hsv_bounds = (C.c_int * 12)(*flat)
         self._h = C.c_void_p()
         self._ctx = _abi.context(device)
         _abi.check(_abi.lib().lc_pipe_create(self._ctx, C.byref(p), C.byref(self._h)))

@@ -34,6 +34,9 @@ extern "C" {
 /* cv2.COLOR_BGR2GRAY / cv2.COLOR_RGB2GRAY */
 #define LC_COLOR_BGR2GRAY 6
 #define LC_COLOR_RGB2GRAY 7
+/* cv2.COLOR_BGR2HSV / cv2.COLOR_RGB2HSV (8-bit, hue in [0, 180)) */
+#define LC_COLOR_BGR2HSV 40
+#define LC_COLOR_RGB2HSV 41
 
 typedef struct lc_ctx lc_ctx;     /* bound to one HIP device; calls on one ctx are serialised by the caller */
 typedef struct lc_pipe lc_pipe;   /* a configured batched pipeline living on a ctx */
@@ -56,6 +59,28 @@ int lc_host_free(void *p);
  *           F1_vo_Lane_Tracking.py:186 (BGR2GRAY). */
 int lc_cvt_gray(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
                 int code, uint8_t *dst, size_t dst_stride);
+
+/* cv2.cvtColor(src, COLOR_BGR2HSV | COLOR_RGB2HSV), 8UC3 -> 8UC3 (H in [0,180), S, V).
+ * Replaces: Simple Lane Detection with OpenCV_6(mp4).py:65. */
+int lc_cvt_hsv(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
+               int code, uint8_t *dst, size_t dst_stride);
+
+/* cv2.inRange(src, lowerb, upperb) on an 8UC3 image with three integer bounds each
+ * (any integers: bounds outside [0, 255] behave as in cv2); dst is 8UC1, 0 / 255.
+ * Replaces: Simple Lane Detection with OpenCV_6(mp4).py:77-78. */
+int lc_in_range3(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
+                 const int *lowerb, const int *upperb, uint8_t *dst, size_t dst_stride);
+
+/* cv2.bitwise_or(a, b) on 8UC1 images.
+ * Replaces: Simple Lane Detection with OpenCV_6(mp4).py:81. */
+int lc_or(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size_t b_stride,
+          uint8_t *dst, size_t dst_stride, int w, int h);
+
+/* cv2.bitwise_and(src, src, mask=mask) on an 8UC3 image with an 8UC1 mask: pixels whose
+ * mask byte is 0 come out black (cv2 allocates a zeroed destination).
+ * Replaces: Simple Lane Detection with OpenCV_6(mp4).py:84. */
+int lc_and3_mask(lc_ctx *ctx, const uint8_t *src, size_t src_stride, const uint8_t *mask, size_t mask_stride,
+                 uint8_t *dst, size_t dst_stride, int w, int h);
 
 /* cv2.GaussianBlur(src, (5,5), 0), 8UC1, BORDER_REFLECT_101.
  * Replaces: F1_vo_Lane_Tracking.py:97. */
@@ -126,6 +151,11 @@ typedef struct lc_pipe_params {
     int want_accumulator;     /* compute the full-vote accumulator */
     int want_segments;        /* run HoughLinesP */
     int keep_intermediates;   /* also materialise gray, blurred and pre-ROI edge images */
+    /* Colour gate of Simple Lane Detection with OpenCV_6(mp4).py:65-88 in front of the gray conversion:
+     * hsv = cvtColor(frame, BGR2HSV); m = inRange(hsv, lo0, hi0) | inRange(hsv, lo1, hi1);
+     * gray = cvtColor(bitwise_and(frame, frame, mask=m), color_code).  LC_BUF_GRAY is that gated gray. */
+    int hsv_gate;             /* 1: apply the gate */
+    int hsv_bounds[12];       /* lo0[3], hi0[3], lo1[3], hi1[3], each in H, S, V order */
 } lc_pipe_params;
 
 /* What lc_pipe_read copies out of a finished slot. */
