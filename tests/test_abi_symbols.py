@@ -53,8 +53,9 @@ def test_python_argument_checks_need_no_gpu():
     with pytest.raises(cv2.error):
         cv2.GaussianBlur(g, (3, 3), 0)
     with pytest.raises(cv2.error):
-        cv2.cvtColor(np.zeros((4, 4, 3), np.uint8), 40)
+        cv2.cvtColor(np.zeros((4, 4, 3), np.uint8), 44)
     with pytest.raises(cv2.error):
         cv2.Canny(g, 1, 2, L2gradient=True)
     assert issubclass(cv2.error, Exception)
     assert (cv2.COLOR_BGR2GRAY, cv2.COLOR_RGB2GRAY, cv2.BORDER_DEFAULT, cv2.LINE_8) == (6, 7, 4, 8)
+    assert (cv2.COLOR_BGR2HSV, cv2.COLOR_RGB2HSV) == (40, 41)

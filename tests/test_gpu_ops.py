@@ -241,7 +241,7 @@ def test_errors(cv2):
     with pytest.raises(Exception):
         cv2.cvtColor(g, cv2.COLOR_BGR2GRAY)                 # not 3-channel
     with pytest.raises(cv2.error):
-        cv2.cvtColor(np.zeros((4, 4, 3), np.uint8), 40)     # unsupported code
+        cv2.cvtColor(np.zeros((4, 4, 3), np.uint8), 44)     # unsupported code (BGR2Lab)
     with pytest.raises(cv2.error):
         cv2.GaussianBlur(g, (3, 3), 0)
     with pytest.raises(cv2.error):
@@ -254,3 +254,14 @@ def test_errors(cv2):
         cv2.HoughLinesP(g, 0, np.pi / 60, 10)
     with pytest.raises(cv2.error):
         cv2.bitwise_and(g, np.zeros((5, 5), np.uint8))
+    c = np.zeros((4, 4, 3), np.uint8)
+    with pytest.raises(cv2.error):
+        cv2.inRange(c, np.array([0.5, 0, 0]), np.array([9, 9, 9]))      # non-integral bound
+    with pytest.raises(cv2.error):
+        cv2.inRange(c, np.array([0, 0]), np.array([9, 9]))              # two bounds for three channels
+    with pytest.raises(cv2.error):
+        cv2.inRange(g, 0, 9)                                            # single-channel source
+    with pytest.raises(cv2.error):
+        cv2.bitwise_and(c, c, mask=np.zeros((5, 5), np.uint8))
+    with pytest.raises(cv2.error):
+        cv2.bitwise_or(g, np.zeros((5, 5), np.uint8))
