@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             const us2 mx = __builtin_elementwise_max(U2(ce), U2(co));
             const int mmax = max((int)(R32(mx) & 0xFFFFu), (int)(R32(mx) >> 16));
             uint32_t nib = 0;    // bits 0-3 strong, bits 8-11 weak
-            if (__ballot(mmax > a.low) != 0) {
+            // only the emitting lanes decide: the halo lanes' magnitudes come from a truncated neighbourhood and
+            // would trigger every row
+            if (__ballot(emits && mmax > a.low) != 0) {
                 // one pair of pixels: m against its two neighbours along the gradient
                 auto nms = [&](uint32_t m, uint32_t dx, uint32_t dy, uint32_t cl, uint32_t cr, uint32_t ul, uint32_t uc,
                                uint32_t ur, uint32_t dl, uint32_t dc, uint32_t dr, uint32_t &sbit, uint32_t &wbit) {
