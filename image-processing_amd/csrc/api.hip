@@ -100,6 +100,7 @@ struct Work {
     bool inter = false;
     DevBuf<uint8_t> bgr, gray, blur, edges, masked;
     DevBuf<uint64_t> planeS, planeW, rowplane;
+    DevBuf<uint64_t> prevbits;    // masked bits last written into `masked` (pipeline slots without intermediates)
     DevBuf<uint32_t> wake;        // two wake-flag arrays of B * tiles words (hysteresis closure)
     DevBuf<int> rounds, rowcount, rowoff, npoints, segcount, status, fallback;
     DevBuf<uint32_t> nz;
@@ -140,6 +141,13 @@ struct Work {
         if ((rc = planeS.alloc((size_t)B * g.plane_words()))) return rc;
         if ((rc = planeW.alloc((size_t)B * g.plane_words()))) return rc;
         if ((rc = rowplane.alloc((size_t)B * g.rowplane_words()))) return rc;
+        if (own_input && !intermediates) {
+            // finalize then writes only what changed since the slot's previous batch: everything starts at zero
+            if ((rc = prevbits.alloc((size_t)B * g.rowplane_words()))) return rc;
+            HIP_TRY(hipMemset(prevbits.p, 0, sizeof(uint64_t) * (size_t)B * g.rowplane_words()));
+            HIP_TRY(hipMemset(rowplane.p, 0, sizeof(uint64_t) * (size_t)B * g.rowplane_words()));
+            HIP_TRY(hipMemset(masked.p, 0, (size_t)B * npix));
+        }
         if ((rc = wake.alloc(2 * (size_t)B * g.TX * g.TY))) return rc;
         if ((rc = rounds.alloc(B))) return rc;
         if ((rc = rowcount.alloc((size_t)B * H))) return rc;
@@ -719,7 +727,7 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     const bool hough = p.want_accumulator || p.want_segments;
     if (!hough) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
-                    w.rowplane.p, w.rowcount.p, es);
+                    w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p);
     (void)hipEventRecord(s.ev[EV_EDGE], es);
     if (hough) {
         launch_rowscan(w.g, n, w.rowcount.p, w.rowoff.p, w.npoints.p, w.r_status, es);

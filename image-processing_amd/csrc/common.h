@@ -76,8 +76,11 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st);
 // roi_bits: one plane shared by all frames, or nullptr
+// prevbits (may be null): the masked bits of the previous call on the same masked_out / rowplane buffers, all
+// zero before the first (like those buffers); with it, and without edges_out, only what changed is written
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits,
-                     uint8_t *edges_out, uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st);
+                     uint8_t *edges_out, uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st,
+                     uint64_t *prevbits = nullptr);
 void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t *dst, size_t n, hipStream_t st);
 void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowplane, int *rowcount, hipStream_t st);
 // points + Hough

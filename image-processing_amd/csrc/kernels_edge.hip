@@ -476,6 +476,48 @@ __global__ __launch_bounds__(256) void k_finalize(Geo g, int ntiles_total, const
     }
 }
 
+// finalize with dirty tracking, for a pipeline slot that writes the same masked-map buffer batch after batch.
+// prevbits holds the masked bits this kernel wrote last time (all zero at first, like the buffer): a 16-pixel
+// group whose bits were zero then and are zero now already holds its sixteen 0 bytes, so only groups that had
+// or have an edge pixel are written -- a few per cent of the map.  The same holds for the plane word handed to
+// the Hough stage (which only ever clears bits of it) and for the row counts (their consumer clears them).
+// One thread per 64-pixel word, words in memory order.
+__global__ __launch_bounds__(256) void k_finalize_sparse(Geo g, size_t nwords, const uint64_t *__restrict__ planeS,
+                                                         const uint64_t *__restrict__ roi_bits, uint64_t *__restrict__ prevbits,
+                                                         uint8_t *__restrict__ masked_out, uint64_t *__restrict__ rowplane,
+                                                         int *__restrict__ rowcount) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nwords) return;
+    const size_t words_per_frame = (size_t)g.TX * g.H;
+    const size_t f = i / words_per_frame, wf = i % words_per_frame;   // wf = y * TX + tx
+    uint64_t M = planeS[i];
+    if (roi_bits) M &= roi_bits[wf];
+    const uint64_t P = prevbits[i];
+    const uint64_t D = M | P;
+    if (D == 0) return;
+    if (rowplane) rowplane[i] = M;
+    if (M != P) prevbits[i] = M;
+    const int y = (int)(wf / g.TX), tx = (int)(wf % g.TX);
+    if (M && rowcount) atomicAdd(&rowcount[f * g.H + y], __popcll(M));
+    const int W = g.W;
+    const bool vec_ok = (W % 16) == 0;
+    const size_t o = f * (size_t)W * g.H + (size_t)y * W + (size_t)tx * TILE;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t d = (uint32_t)(D >> (16 * q)) & 0xFFFFu, mb = (uint32_t)(M >> (16 * q)) & 0xFFFFu;
+        const int x = tx * TILE + 16 * q;
+        if (d == 0 || x >= W) continue;
+        if (vec_ok) {
+            uint4 ms;
+            ms.x = expand4(mb & 15); ms.y = expand4((mb >> 4) & 15); ms.z = expand4((mb >> 8) & 15); ms.w = expand4(mb >> 12);
+            *reinterpret_cast<uint4 *>(masked_out + o + 16 * q) = ms;
+        } else {
+            const int n = W - x < 16 ? W - x : 16;
+            for (int j = 0; j < n; j++) masked_out[o + 16 * q + j] = (mb >> j) & 1 ? 255 : 0;
+        }
+    }
+}
+
 // bitwise_and with an optional mask (dst = 0 where mask == 0)
 __global__ __launch_bounds__(256) void k_and(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
                                              const uint8_t *__restrict__ mask, uint8_t *__restrict__ dst, size_t n) {
@@ -562,7 +604,13 @@ void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *pla
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,
-                     uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st) {
+                     uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st, uint64_t *prevbits) {
+    if (prevbits && !edges_out && masked_out) {
+        const size_t nwords = (size_t)g.TX * g.H * nframes;
+        hipLaunchKernelGGL(k_finalize_sparse, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, g, nwords, planeS, roi_bits,
+                           prevbits, masked_out, rowplane, rowcount);
+        return;
+    }
     int nt = g.TX * g.TY * nframes;
     hipLaunchKernelGGL(k_finalize, dim3((nt + 3) / 4), dim3(256), 0, st, g, nt, planeS, roi_bits, edges_out, masked_out,
                        rowplane, rowcount);

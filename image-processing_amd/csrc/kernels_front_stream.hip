@@ -160,11 +160,8 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     Pair Mw[3] = {}, Nw[3] = {};                   // magnitudes; Nw.e = left neighbours of the e pixels, Nw.o = right neighbours of the o pixels
     Pair DXw[3] = {}, DYw[3] = {};                 // gradients
 
-    // Memory traffic is issued once per group of three rows, at the top of the group: the loads of the
-    // NEXT group's rows and the plane bytes of the PREVIOUS group.  The only wait for memory (the
-    // hardware counts loads and stores in one counter) then covers operations issued a whole group
-    // earlier, so neither the HBM latency nor the store acknowledgements stall the arithmetic.
-    uint32_t Lc[3][3] = {}, Ln[3][3] = {};         // rows of the current / next group
+    uint32_t L[3][3] = {};                         // source rows of a group: consumed by the gray conversion at the
+                                                   // top of the group, then reloaded with the next group's rows
     uint32_t pend[3] = {};                         // plane bytes of the group just finished (strong | weak << 8)
     auto load_row = [&](int v, uint32_t (&r)[3]) {
         const int rs = BLUR ? reflect101s(v, H) : (v < 0 ? 0 : (v >= H ? H - 1 : v));
@@ -184,11 +181,9 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
 
     const int vend = y1 - 1 + DB + 2;
 
-    auto step = [&](auto phase, const int v) {
-        constexpr int P = decltype(phase)::value, PREV = (P + 2) % 3, OLD = (P + 1) % 3;
-        const uint32_t w0 = Lc[P][0], w1 = Lc[P][1], w2 = Lc[P][2];
-
-        // ---- gray: 4 pixels -> one packed dword ------------------------------------------------
+    // ---- gray: 4 pixels (12 bytes) of source row v -> one packed dword ------------------------------
+    auto gray_row = [&](const uint32_t (&r)[3], const int v) -> uint32_t {
+        const uint32_t w0 = r[0], w1 = r[1], w2 = r[2];
         const uint32_t p0 = w0, p1 = alignbyte(w1, w0, 3), p2 = alignbyte(w2, w1, 2), p3 = w2 >> 8;
         const uint32_t t0 = (dot4(p0, a.k_hi, 0) << 8) + dot4(p0, a.k_lo, 1u << 15);
         const uint32_t t1 = (dot4(p1, a.k_hi, 0) << 8) + dot4(p1, a.k_lo, 1u << 15);
@@ -203,6 +198,11 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         if (a.gray_out && v >= y0 && v < y1) {
             if (inimg && emits) *reinterpret_cast<uint32_t *>(a.gray_out + (size_t)f * W * H + (size_t)v * W + px) = G;
         }
+        return G;
+    };
+
+    auto step = [&](auto phase, const int v, uint32_t G) {
+        constexpr int P = decltype(phase)::value, PREV = (P + 2) % 3, OLD = (P + 1) % 3;
 
         // ---- Sobel input row (blurred row v-2, or the gray row itself) as pairs -----------------
         uint32_t be, bo;
@@ -252,17 +252,19 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         // ---- Sobel, vertical part, and magnitude of row m = b - 1 --------------------------------
         const int m_row = v - DB - 1;
         {
-            if (m_row == 0) { Dw[OLD] = Dw[PREV]; Sw[OLD] = Sw[PREV]; }        // replicate above
-            if (m_row == H - 1) { Dw[P] = Dw[PREV]; Sw[P] = Sw[PREV]; }        // replicate below
+            // (the empty asm statements keep these two rare cases scalar branches instead of per-row selects)
+            if (m_row == 0) { asm volatile(""); Dw[OLD] = Dw[PREV]; Sw[OLD] = Sw[PREV]; }        // replicate above
+            if (m_row == H - 1) { asm volatile(""); Dw[P] = Dw[PREV]; Sw[P] = Sw[PREV]; }        // replicate below
             DXw[P].e = pkmad2(Dw[PREV].e, pkadd(Dw[OLD].e, Dw[P].e));
             DXw[P].o = pkmad2(Dw[PREV].o, pkadd(Dw[OLD].o, Dw[P].o));
             DYw[P].e = pksub(Sw[P].e, Sw[OLD].e);
             DYw[P].o = pksub(Sw[P].o, Sw[OLD].o);
-            const bool live = inimg && m_row >= 0 && m_row < H;
-            const uint32_t mge = pkadd(pkabs(DXw[P].e), pkabs(DYw[P].e));
-            const uint32_t mgo = pkadd(pkabs(DXw[P].o), pkabs(DYw[P].o));
-            Mw[P].e = live ? mge : 0u;
-            Mw[P].o = live ? mgo : 0u;
+            // magnitudes outside the image are zero: whole rows above / below it (rare, a scalar branch) and the
+            // lanes left / right of it in the first and last strips
+            Mw[P].e = pkadd(pkabs(DXw[P].e), pkabs(DYw[P].e));
+            Mw[P].o = pkadd(pkabs(DXw[P].o), pkabs(DYw[P].o));
+            if (m_row < 0 || m_row >= H) { asm volatile(""); Mw[P].e = 0u; Mw[P].o = 0u; }
+            else if (has_border) { Mw[P].e = inimg ? Mw[P].e : 0u; Mw[P].o = inimg ? Mw[P].o : 0u; }
             Nw[P].e = alignbyte(Mw[P].o, from_left(Mw[P].o), 2);
             Nw[P].o = alignbyte(from_right(Mw[P].e), Mw[P].e, 2);
         }
@@ -300,24 +302,27 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
                 nms(co, DXw[PREV].o, DYw[PREV].o, ce, Nw[PREV].o, Mw[OLD].e, Mw[OLD].o, Nw[OLD].o, Mw[P].e, Mw[P].o, Nw[P].o, so, wo);
                 const uint32_t xs = se | (so << 1), xw = we | (wo << 1);   // bits 0,1 = px0,px1; bits 16,17 = px2,px3
                 nib = ((xs | (xs >> 14)) & 0xFu) | (((xw | (xw >> 14)) & 0xFu) << 8);
+                // two lanes make a byte of each plane: odd lane 2i+1 takes lane 2i+2's nibble
+                nib |= from_right(nib) << 4;
             }
-            // two lanes make a byte of each plane: odd lane 2i+1 takes lane 2i+2's nibble
-            pend[P] = nib | (from_right(nib) << 4);
+            pend[P] = nib;
         }
     };
 
+    // Memory traffic is issued once per group of three rows, near the top of the group: the gray conversion
+    // first consumes the group's source rows, then the loads of the NEXT group's rows go out into the same
+    // registers, together with the plane bytes of the PREVIOUS group.  The only wait for memory (the hardware
+    // counts loads and stores in one counter) then covers operations issued a whole group earlier, so neither
+    // the HBM latency nor the store acknowledgements stall the arithmetic.
     int v = y0 - (DB + 2);
-    load_row(v, Ln[0]); load_row(v + 1, Ln[1]); load_row(v + 2, Ln[2]);
+    load_row(v, L[0]); load_row(v + 1, L[1]); load_row(v + 2, L[2]);
     for (; v <= vend; v += 3) {
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int q = 0; q < 3; q++) Lc[p][q] = Ln[p][q];
-        if (v + 3 <= vend) { load_row(v + 3, Ln[0]); load_row(v + 4, Ln[1]); load_row(v + 5, Ln[2]); }
+        const uint32_t G0 = gray_row(L[0], v), G1 = gray_row(L[1], v + 1), G2 = gray_row(L[2], v + 2);
+        if (v + 3 <= vend) { load_row(v + 3, L[0]); load_row(v + 4, L[1]); load_row(v + 5, L[2]); }
         store_row(v - 3 - DB - 2, pend[0]); store_row(v - 2 - DB - 2, pend[1]); store_row(v - 1 - DB - 2, pend[2]);
-        step(Phase<0>{}, v);
-        step(Phase<1>{}, v + 1);
-        step(Phase<2>{}, v + 2);
+        step(Phase<0>{}, v, G0);
+        step(Phase<1>{}, v + 1, G1);
+        step(Phase<2>{}, v + 2, G2);
     }
     store_row(v - 3 - DB - 2, pend[0]); store_row(v - 2 - DB - 2, pend[1]); store_row(v - 1 - DB - 2, pend[2]);
 }
