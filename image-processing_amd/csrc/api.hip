@@ -102,7 +102,7 @@ struct Work {
     DevBuf<uint64_t> planeS, planeW, rowplane;
     DevBuf<uint64_t> prevbits;    // masked bits last written into `masked` (pipeline slots without intermediates)
     DevBuf<uint32_t> wake;        // two wake-flag arrays of B * tiles words (hysteresis closure)
-    DevBuf<int> rounds, rowcount, rowoff, npoints, segcount, status, fallback;
+    DevBuf<int> rounds, rowcount, npoints, segcount, status, fallback;
     DevBuf<uint32_t> nz;
     int nz_cap = 0;
     DevBuf<int32_t> acc_full, acc_ppht, seg;
@@ -154,7 +154,6 @@ struct Work {
         // both are left all zero by their last reader (hysteresis closure / point scatter), so once is enough
         HIP_TRY(hipMemset(wake.p, 0, sizeof(uint32_t) * 2 * (size_t)B * g.TX * g.TY));
         HIP_TRY(hipMemset(rowcount.p, 0, sizeof(int) * (size_t)B * H));
-        if ((rc = rowoff.alloc((size_t)B * H))) return rc;
         if ((rc = npoints.alloc(B))) return rc;
         if ((rc = segcount.alloc(B))) return rc;
         if ((rc = status.alloc(1))) return rc;
@@ -270,8 +269,7 @@ int points_from_bytes(lc_ctx *ctx, int *npoints_host) {
     Work &w = ctx->work;
     hipStream_t st = ctx->stream;
     launch_pack_nonzero(ctx->tmpA.p, w.g, 1, w.rowplane.p, w.rowcount.p, st);
-    launch_rowscan(w.g, 1, w.rowcount.p, w.rowoff.p, w.npoints.p, nullptr, st);
-    launch_scatter(w.g, 1, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, st);
+    launch_points(w.g, 1, w.rowplane.p, w.rowcount.p, w.nz.p, w.nz_cap, w.npoints.p, nullptr, st);
     if (npoints_host) {
         HIP_TRY(hipMemcpyAsync(npoints_host, w.npoints.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -730,8 +728,7 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
                     w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p);
     (void)hipEventRecord(s.ev[EV_EDGE], es);
     if (hough) {
-        launch_rowscan(w.g, n, w.rowcount.p, w.rowoff.p, w.npoints.p, w.r_status, es);
-        launch_scatter(w.g, n, w.rowplane.p, w.rowcount.p, w.rowoff.p, w.nz.p, w.nz_cap, es);
+        launch_points(w.g, n, w.rowplane.p, w.rowcount.p, w.nz.p, w.nz_cap, w.npoints.p, w.r_status, es);
     }
     (void)hipEventRecord(s.ev[EV_POINTS], es);
     // The full-vote accumulator depends only on the point list.  With segments wanted, the HoughLinesP kernel

@@ -84,9 +84,10 @@ void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t 
 void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t *dst, size_t n, hipStream_t st);
 void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowplane, int *rowcount, hipStream_t st);
 // points + Hough
-void launch_rowscan(Geo g, int nframes, const int *rowcount, int *rowoff, int *npoints, int *status, hipStream_t st);
-void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, const int *rowoff, uint32_t *nz,
-                    int nz_cap, hipStream_t st);
+// edge points of each frame in scan order from its bit plane and per-row counts (which it clears); also
+// zeroes *status (may be null) for the Hough kernels behind it
+void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, uint32_t *nz, int nz_cap, int *npoints,
+                   int *status, hipStream_t st);
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
                  int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st);
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,

@@ -17,63 +17,72 @@ __device__ __forceinline__ int rho_bin(int x, int y, float c, float s, int half)
     return __float2int_rn(__fadd_rn(__fmul_rn((float)x, c), __fmul_rn((float)y, s))) + half;
 }
 
-// exclusive scan of the per-row point counts of one frame
-__global__ __launch_bounds__(256) void k_rowscan(int H, const int *__restrict__ rowcount, int *__restrict__ rowoff,
-                                                 int *__restrict__ npoints, int *__restrict__ status) {
-    __shared__ int part[256];
-    const int f = blockIdx.x, tid = threadIdx.x;
-    if (status && f == 0 && tid == 0) *status = 0;   // the Hough kernels behind this one OR their error bits into it
-    const int per = (H + 255) / 256;
-    const int r0 = tid * per, r1 = min(H, r0 + per);
-    int s = 0;
-    for (int r = r0; r < r1; r++) s += rowcount[(size_t)f * H + r];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        int v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int off = part[tid] - s;
-    for (int r = r0; r < r1; r++) {
-        rowoff[(size_t)f * H + r] = off;
-        off += rowcount[(size_t)f * H + r];
-    }
-    if (tid == 255) npoints[f] = part[255];
-}
+// Ordered compaction of a frame's edge points: (x | y << 16) in row-major scan order, what OpenCV's loops
+// over the edge map produce.  One 16-wavefront workgroup per frame.  A wavefront owns a contiguous band of
+// rows; the per-row counts give its total (and are cleared: this kernel is their last reader), a scan over
+// the 16 totals its first position, and then the band's plane words -- contiguous in memory and already in
+// scan order -- are taken 64 at a time: popcount, wave scan, scatter.  Bands without points leave at once.
+constexpr int POINTS_WAVES = 16;
 
-// one wavefront per (frame, row): points in left-to-right order at the row's offset.  Empty rows
-// (most of the image outside the ROI) leave at once; otherwise lane l takes word l of the row, a
-// wave scan of the popcounts places each word's points.
-__global__ __launch_bounds__(256) void k_scatter(Geo g, int nframes, const uint64_t *__restrict__ rowplane,
-                                                 int *__restrict__ rowcount, const int *__restrict__ rowoff,
-                                                 uint32_t *__restrict__ nz, int nz_cap) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (long long)nframes * g.H) return;
-    if (rowcount[row] == 0) return;
-    if (lane == 0) rowcount[row] = 0;      // last reader: the counts are zero again for the next batch
-    const int f = (int)(row / g.H), y = (int)(row % g.H);
-    int off = rowoff[row];
+__global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint64_t *__restrict__ rowplane,
+                                                               int *__restrict__ rowcount, uint32_t *__restrict__ nz, int nz_cap,
+                                                               int *__restrict__ npoints, int *__restrict__ status) {
+    __shared__ int tot[POINTS_WAVES];
+    const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (status && f == 0 && threadIdx.x == 0) *status = 0;   // the Hough kernels behind this one OR their error bits into it
+    const int H = g.H, TX = g.TX;
+    const int rpw = (H + POINTS_WAVES - 1) / POINTS_WAVES;
+    const int r0 = min(H, wv * rpw), r1 = min(H, r0 + rpw);
+    int s = 0;
+    for (int r = r0 + lane; r < r1; r += 64) {
+        const int c = rowcount[(size_t)f * H + r];
+        if (c) rowcount[(size_t)f * H + r] = 0;
+        s += c;
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) tot[wv] = s;
+    __syncthreads();
+    int off = 0, all = 0;
+    for (int i = 0; i < POINTS_WAVES; i++) {
+        const int t = tot[i];
+        off += i < wv ? t : 0;
+        all += t;
+    }
+    if (threadIdx.x == 0) npoints[f] = all;
+    if (s == 0) return;
+    const uint64_t *wp = rowplane + ((size_t)f * H + r0) * TX;
+    const int nwords = (r1 - r0) * TX;
     uint32_t *out = nz + (size_t)f * nz_cap;
-    for (int tx0 = 0; tx0 < g.TX; tx0 += 64) {
-        const int tx = tx0 + lane;
-        uint64_t w = tx < g.TX ? rowplane[(size_t)row * g.TX + tx] : 0;
-        const int c = __popcll(w);
-        int incl = c;   // inclusive scan over the lanes
-        for (int d = 1; d < 64; d <<= 1) {
-            int v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
+    constexpr int UNR = 8;   // words per lane in flight: the loads of a batch go out together
+    for (int k0 = 0; k0 < nwords; k0 += 64 * UNR) {
+        uint64_t wq[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; j++) {
+            const int idx = k0 + 64 * j + lane;
+            wq[j] = idx < nwords ? wp[idx] : 0;
         }
-        int pos = off + incl - c;
-        while (w) {
-            int b = __builtin_ctzll(w);
-            if (pos < nz_cap) out[pos] = (uint32_t)(tx * 64 + b) | ((uint32_t)y << 16);
-            pos++;
-            w &= w - 1;
+#pragma unroll
+        for (int j = 0; j < UNR; j++) {
+            uint64_t w = wq[j];
+            if (__ballot(w != 0) == 0) continue;
+            const int idx = k0 + 64 * j + lane;
+            const int c = __popcll(w);
+            int incl = c;   // inclusive scan over the lanes
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            int pos = off + incl - c;
+            const int rr = idx / TX;
+            const uint32_t hi = (uint32_t)(r0 + rr) << 16, xb = (uint32_t)(idx - rr * TX) * 64u;
+            while (w) {
+                const int b = __builtin_ctzll(w);
+                if (pos < nz_cap) out[pos] = (xb + b) | hi;
+                pos++;
+                w &= w - 1;
+            }
+            off += __shfl(incl, 63);
         }
-        off += __shfl(incl, 63);
     }
 }
 
@@ -1017,15 +1026,9 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
 
 }  // namespace
 
-void launch_rowscan(Geo g, int nframes, const int *rowcount, int *rowoff, int *npoints, int *status, hipStream_t st) {
-    hipLaunchKernelGGL(k_rowscan, dim3(nframes), dim3(256), 0, st, g.H, rowcount, rowoff, npoints, status);
-}
-
-void launch_scatter(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, const int *rowoff, uint32_t *nz,
-                    int nz_cap, hipStream_t st) {
-    long long rows = (long long)nframes * g.H;
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, g, nframes, rowplane, rowcount, rowoff, nz,
-                       nz_cap);
+void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, uint32_t *nz, int nz_cap, int *npoints,
+                   int *status, hipStream_t st) {
+    hipLaunchKernelGGL(k_points, dim3(nframes), dim3(64 * POINTS_WAVES), 0, st, g, rowplane, rowcount, nz, nz_cap, npoints, status);
 }
 
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
