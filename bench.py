@@ -181,7 +181,7 @@ def main():
                          "note": "duration = HIP events around the kernel on the stream it runs on, inside the timed region "
                                  "(HoughLinesP of the previous batch runs beside it); traffic = FETCH_SIZE (x2, gfx950) + "
                                  "WRITE_SIZE per launch from the committed rocprofv3 PMC passes of the same launch shape"},
-            "roofline_edge_stage": {"kernels": "k_front_stream + k_hyst_first + k_hyst_close + k_finalize_sparse",
+            "roofline_edge_stage": {"kernels": "k_front_stream + k_hysteresis + k_finalize_sparse",
                                     "algorithmic_bytes_per_launch": stage_bytes, "launch_ms": round(edge_ms, 4),
                                     "achieved": round(stage_bytes / (edge_ms * 1e-3) / 1e9, 1),
                                     "frac": round(stage_bytes / (edge_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},

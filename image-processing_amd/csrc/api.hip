@@ -481,7 +481,7 @@ int lc_canny(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, d
     Work &wk = ctx->work;
     if ((rc = up2d(ctx->tmpA.p, src, w, h, src_stride, ctx->stream))) return rc;
     launch_front(ctx->tmpA.p, (size_t)w * h, 0, LC_COLOR_BGR2GRAY, false, wk.g, 1, low, high, wk.planeS.p, wk.planeW.p,
-                 nullptr, nullptr, ctx->stream);
+                 wk.wake.p, nullptr, nullptr, ctx->stream);
     launch_hysteresis(wk.g, 1, wk.planeS.p, wk.planeW.p, wk.wake.p, wk.rounds.p, ctx->stream);
     launch_finalize(wk.g, 1, wk.planeS.p, nullptr, ctx->tmpB.p, nullptr, nullptr, nullptr, ctx->stream);
     return down2d(dst, dst_stride, ctx->tmpB.p, w, h, ctx->stream);
@@ -794,7 +794,7 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     }
     HIP_TRY(hipEventRecord(s.ev[EV_ESTART], es));
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
-                 w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
+                 w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
                  pp->has_gate ? &pp->gate : nullptr, pp->ctx->hsv_tab.p, w.gray.p);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }

@@ -60,19 +60,23 @@ void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_
 bool front_stream_supported(Geo g);
 // gate (may be null): the colour gate applied to the frame before the gray conversion; tab as above
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
-                         uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, int rows_per_unit,
-                         const GateDev *gate, const int *tab, hipStream_t st);
+                         uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
+                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st);
 void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st);
 // in_kind: 0 = gray bytes in, 1 = interleaved 3-channel bytes in
 // gate (may be null, 3-channel input only): colour gate in front of the gray conversion.  Frames the
 // streaming kernel cannot take go through a gated gray image first: gate_gray (nframes * W * H bytes)
 // is where it is put, and it may be the same buffer as gray_out.
+// wake: nframes * TX * TY flags, all zero on entry; the tiles that hold a weak pixel are set (launch_hysteresis
+// consumes and clears them).
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes,
-                  int low, int high, uint64_t *planeS, uint64_t *planeW,
+                  int low, int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake,
                   uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
                   const GateDev *gate = nullptr, const int *tab = nullptr, uint8_t *gate_gray = nullptr);
-// hysteresis to the fixed point: a chip-wide first round, then one workgroup per frame closes
-// the chains that cross tile borders; rounds[f] receives the closure rounds frame f needed
+// hysteresis to the fixed point: one workgroup per frame floods the tiles flagged in wake (by the front
+// kernel: those with weak pixels), then repeats over the tiles whose neighbours gained a strong border pixel
+// until a round flags none; rounds[f] receives the rounds frame f needed.  wake holds two arrays of
+// nframes * tiles flags (the second all zero on entry); both are all zero on exit.
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st);
 // roi_bits: one plane shared by all frames, or nullptr

@@ -90,8 +90,8 @@ constexpr int FT_W = 64, FT_H = 32, FNT = 256;
 template <bool IN_BGR, bool BLUR>
 __global__ __launch_bounds__(FNT) void k_front(const uint8_t *__restrict__ src, size_t src_bytes, Geo g, int k0, int k1,
                                                int k2, int low, int high, uint64_t *__restrict__ planeS,
-                                               uint64_t *__restrict__ planeW, uint8_t *__restrict__ gray_out,
-                                               uint8_t *__restrict__ blur_out) {
+                                               uint64_t *__restrict__ planeW, uint32_t *__restrict__ wake,
+                                               uint8_t *__restrict__ gray_out, uint8_t *__restrict__ blur_out) {
     constexpr int HALO = BLUR ? 4 : 2;
     constexpr int GW = FT_W + 2 * HALO, GH = FT_H + 2 * HALO;   // gray region
     constexpr int SW = FT_W + 4, SH = FT_H + 4;                 // Sobel-input region (halo 2)
@@ -242,7 +242,11 @@ __global__ __launch_bounds__(FNT) void k_front(const uint8_t *__restrict__ src, 
             }
         }
         uint64_t bs = __ballot(strong), bw = __ballot(weak);
-        if (c == 0 && y < H) { planeS[plane_base + (size_t)r * g.TX] = bs; planeW[plane_base + (size_t)r * g.TX] = bw; }
+        if (c == 0 && y < H) {
+            planeS[plane_base + (size_t)r * g.TX] = bs;
+            planeW[plane_base + (size_t)r * g.TX] = bw;
+            if (bw) wake[((size_t)f * g.TY + (y >> 6)) * g.TX + (tx0 >> 6)] = 1u;
+        }
     }
 }
 
@@ -356,34 +360,21 @@ __device__ __forceinline__ int nb_tile(const Geo &g, int ty, int tx, int k) {
     return (ty + dys[k]) * g.TX + (tx + dxs[k]);
 }
 
-// round 0: every tile of every frame, one wavefront each, the whole chip busy
-constexpr int HY_WAVES = 4;
-__global__ __launch_bounds__(64 * HY_WAVES) void k_hyst_first(Geo g, int ntiles_total, uint64_t *__restrict__ planeS,
-                                                             const uint64_t *__restrict__ planeW,
-                                                             uint32_t *__restrict__ wake) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * HY_WAVES + (threadIdx.x >> 6);   // global tile index over all frames
-    if (t >= ntiles_total) return;
-    const int tiles_per_frame = g.TX * g.TY;
-    const int f = t / tiles_per_frame, tt = t % tiles_per_frame;
-    const int ty = tt / g.TX, tx = tt % g.TX;
-    const unsigned m = hyst_tile(g, f, ty, tx, planeS, planeW, lane);
-    if (lane < 8 && ((m >> lane) & 1)) wake[(size_t)f * tiles_per_frame + nb_tile(g, ty, tx, lane)] = 1;
-}
-
-// closure: one workgroup per frame repeats rounds over the woken tiles until none is woken.
-// All cross-tile hand-offs stay inside the workgroup (barriers + L2-served words), so the fixed
-// point is reached on the device with no host round trip.  The wake flags live in global memory
-// (two arrays per frame, swapped every round) and the kernel keeps 4 bytes of LDS, so it can share
-// a CU with kernels of other batches that fill the LDS.
-constexpr int HC_THREADS = 1024;
+// One workgroup per frame runs the rounds.  The first round's work list comes from the front kernel, which
+// flags every tile it stores a weak pixel into; later rounds take the tiles woken by their neighbours, until a
+// round wakes none.  All cross-tile hand-offs stay inside the workgroup (barriers + L2-served words), so the
+// fixed point is reached on the device with no host round trip.  The flags live in global memory (two arrays
+// per frame, swapped every round) and the kernel keeps 4 bytes of LDS, so it can share a CU with kernels of
+// other batches that fill the LDS.  A wavefront reads 64 flags at once, lane l that of tile 16 l + wave:
+// neighbouring tiles (a lane marking crosses several in a row) go to different wavefronts.
+constexpr int HC_THREADS = 1024, HC_WAVES = HC_THREADS / 64;
 __device__ __forceinline__ uint32_t ldF(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void stF(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ __launch_bounds__(HC_THREADS) void k_hyst_close(Geo g, uint64_t *__restrict__ planeS,
+__global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__restrict__ planeS,
                                                            const uint64_t *__restrict__ planeW,
                                                            uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
                                                            int *__restrict__ rounds_out) {
@@ -402,12 +393,18 @@ __global__ __launch_bounds__(HC_THREADS) void k_hyst_close(Geo g, uint64_t *__re
         __syncthreads();
         if (tid == 0) any = 0;
         __syncthreads();
-        for (int t = wave; t < ntile; t += HC_THREADS / 64) {
-            if (!ldF(cur + t)) continue;
-            if (lane == 0) stF(cur + t, 0);           // this array is next round's target
-            const int ty = t / g.TX, tx = t % g.TX;
-            const unsigned m = hyst_tile(g, f, ty, tx, planeS, planeW, lane);
-            if (lane < 8 && ((m >> lane) & 1)) { stF(nxt + nb_tile(g, ty, tx, lane), 1); any = 1; }
+        for (int base = 0; base < ntile; base += HC_THREADS) {
+            const int t = base + lane * HC_WAVES + wave;
+            const bool flagged = t < ntile && ldF(cur + t) != 0;
+            if (flagged) stF(cur + t, 0);             // this array is next round's target
+            uint64_t todo = __ballot(flagged);
+            while (todo) {
+                const int tt = base + __builtin_ctzll(todo) * HC_WAVES + wave;
+                todo &= todo - 1;
+                const int ty = tt / g.TX, tx = tt % g.TX;
+                const unsigned m = hyst_tile(g, f, ty, tx, planeS, planeW, lane);
+                if (lane < 8 && ((m >> lane) & 1)) { stF(nxt + nb_tile(g, ty, tx, lane), 1); any = 1; }
+            }
         }
         __threadfence_block();
         __syncthreads();
@@ -571,12 +568,12 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 }
 
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes, int low,
-                  int high, uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
-                  const GateDev *gate, const int *tab, uint8_t *gate_gray) {
+                  int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
+                  hipStream_t st, const GateDev *gate, const int *tab, uint8_t *gate_gray) {
     static const char *force_tiled = getenv("LANECV_FRONT_TILED");       // diagnostics: use the tiled kernel everywhere
     static const char *rows_env = getenv("LANECV_FRONT_ROWS");           // tuning: rows per streaming unit
     if (in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1')) {
-        launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, gray_out, blur_out,
+        launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, wake, gray_out, blur_out,
                             rows_env ? atoi(rows_env) : 0, gate, tab, st);
         return;
     }
@@ -588,7 +585,7 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
     }
     int k0 = code == 6 ? 3735 : 9798, k2 = code == 6 ? 9798 : 3735;
     dim3 grid(g.TX, (g.H + FT_H - 1) / FT_H, nframes), block(FNT);
-#define LC_FRONT(B, L) hipLaunchKernelGGL((k_front<B, L>), grid, block, 0, st, src, src_bytes, g, k0, 19235, k2, low, high, planeS, planeW, gray_out, blur_out)
+#define LC_FRONT(B, L) hipLaunchKernelGGL((k_front<B, L>), grid, block, 0, st, src, src_bytes, g, k0, 19235, k2, low, high, planeS, planeW, wake, gray_out, blur_out)
     if (in_kind == 1) { if (blur) LC_FRONT(true, true); else LC_FRONT(true, false); }
     else { if (blur) LC_FRONT(false, true); else LC_FRONT(false, false); }
 #undef LC_FRONT
@@ -596,11 +593,10 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st) {
-    // wake holds two flag arrays of nframes * tiles words each.  They are all zero on entry (zeroed when
-    // allocated) and again on exit: the closure clears every flag it consumes and stops when a round sets none.
-    const int per = g.TX * g.TY, nt = per * nframes;
-    hipLaunchKernelGGL(k_hyst_first, dim3((nt + HY_WAVES - 1) / HY_WAVES), dim3(64 * HY_WAVES), 0, st, g, nt, planeS, planeW, wake);
-    hipLaunchKernelGGL(k_hyst_close, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds);
+    // wake holds two flag arrays of nframes * tiles words each.  The second is all zero on entry and both are on
+    // exit (zeroed when allocated): the kernel clears every flag it consumes and stops when a round sets none.
+    const int nt = g.TX * g.TY * nframes;
+    hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,

@@ -105,6 +105,7 @@ struct FrontArgs {
     int low, high;
     uint64_t *planeS, *planeW;
     uint8_t *gray_out, *blur_out;
+    uint32_t *wake;          // per 64x64 tile: set where a weak pixel is stored (the hysteresis kernel's work list)
     int rows_per_unit, nseg, nstrips, nunits;
     const int *gate_tab;     // GATE only: the HSV reciprocal tables in device memory
     GateDev gate;
@@ -173,8 +174,10 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             uint8_t *rowS = reinterpret_cast<uint8_t *>(a.planeS) + ((size_t)f * H + n_row) * TX * 8;
             uint8_t *rowW = reinterpret_cast<uint8_t *>(a.planeW) + ((size_t)f * H + n_row) * TX * 8;
             if (stores) {
+                const uint32_t wb = (both >> 8) & 0xFF;
                 rowS[bi] = (uint8_t)(both & 0xFF);
-                rowW[bi] = (uint8_t)((both >> 8) & 0xFF);
+                rowW[bi] = (uint8_t)wb;
+                if (wb) a.wake[((size_t)f * a.g.TY + (n_row >> 6)) * TX + (bi >> 3)] = 1u;
             }
         }
     };
@@ -332,9 +335,10 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
 bool front_stream_supported(Geo g) { return g.W % 4 == 0 && g.W >= 8; }
 
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
-                         uint64_t *planeS, uint64_t *planeW, uint8_t *gray_out, uint8_t *blur_out, int rows_per_unit,
-                         const GateDev *gate, const int *tab, hipStream_t st) {
+                         uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
+                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st) {
     FrontArgs a;
+    a.wake = wake;
     a.gate_tab = tab;
     if (gate) a.gate = *gate; else a.gate = GateDev{};
     a.src = src; a.g = g; a.low = low; a.high = high;

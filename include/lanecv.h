@@ -195,8 +195,8 @@ int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes
 int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms);
 /* Device pointer of a slot's own input buffer (for callers that fill it on the device). */
 int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr);
-/* Hysteresis diagnostics of the slot's last batch: cross-tile closure rounds, maximum over the
- * frames and total. */
+/* Hysteresis diagnostics of the slot's last batch: rounds until the fixed point (the first
+ * included), maximum over the frames and total. */
 int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_total);
 /* Synchronous copy of nframes host frames into the slot's own input buffer, nothing else:
  * a later lc_pipe_submit_device on that pointer then runs with the input resident in HBM. */
