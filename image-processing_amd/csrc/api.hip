@@ -101,6 +101,7 @@ struct Work {
     DevBuf<uint8_t> bgr, gray, blur, edges, masked;
     DevBuf<uint64_t> planeS, planeW, rowplane;
     DevBuf<uint64_t> prevbits;    // masked bits last written into `masked` (pipeline slots without intermediates)
+    DevBuf<uint8_t> src_in;       // frames at their source size when the pipeline resizes them first
     DevBuf<uint32_t> wake;        // two wake-flag arrays of B * tiles words (hysteresis closure)
     DevBuf<int> rounds, rowcount, npoints, segcount, status, fallback;
     DevBuf<uint32_t> nz;
@@ -208,6 +209,8 @@ struct lc_ctx {
     DevBuf<uint8_t> tmpA, tmpB, tmpC, tmpD;
     DevBuf<uint8_t> tmp3;     // a 3-channel image of the current size (colour gate per-op calls)
     DevBuf<int> hsv_tab;      // sdiv[256], hdiv[256] of the 8-bit HSV conversion
+    DevBuf<uint8_t> rs_src, rs_dst;   // resize: source and destination images
+    DevBuf<int> rs_tab;
 };
 
 namespace {
@@ -453,6 +456,26 @@ int lc_and3_mask(lc_ctx *ctx, const uint8_t *src, size_t src_stride, const uint8
     return down2d(dst, dst_stride, ctx->tmp3.p, 3 * (size_t)w, h, ctx->stream);
 }
 
+int lc_resize_linear(lc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, int channels, uint8_t *dst, int dw, int dh,
+                     size_t dst_stride) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if (channels != 1 && channels != 3) return fail(LC_EUNSUPPORTED, "resize: 1 or 3 channels are supported, got %d", channels);
+    if ((rc = check_image(src, sw, sh, src_stride, (size_t)sw * channels, "resize src"))) return rc;
+    if ((rc = check_image(dst, dw, dh, dst_stride, (size_t)dw * channels, "resize dst"))) return rc;
+    const size_t sn = (size_t)sw * sh * channels, dn = (size_t)dw * dh * channels;
+    if (ctx->rs_src.n < sn && (rc = ctx->rs_src.alloc(sn))) return rc;
+    if (ctx->rs_dst.n < dn && (rc = ctx->rs_dst.alloc(dn))) return rc;
+    const size_t tn = 2 * ((size_t)dw + dh);
+    if (ctx->rs_tab.n < tn && (rc = ctx->rs_tab.alloc(tn))) return rc;
+    std::vector<int> tab(tn);
+    const bool area2 = resize_tables_host(sw, sh, dw, dh, tab.data(), tab.data() + dw, tab.data() + 2 * dw, tab.data() + 2 * dw + dh);
+    HIP_TRY(hipMemcpyAsync(ctx->rs_tab.p, tab.data(), sizeof(int) * tn, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = up2d(ctx->rs_src.p, src, (size_t)sw * channels, sh, src_stride, ctx->stream))) return rc;
+    launch_resize_linear(ctx->rs_src.p, sw, sh, channels, 1, ctx->rs_dst.p, dw, dh, ctx->rs_tab.p, area2, ctx->stream);
+    return down2d(dst, dst_stride, ctx->rs_dst.p, (size_t)dw * channels, dh, ctx->stream);   // synchronises: tab may go
+}
+
 int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, uint8_t *dst, size_t dst_stride) {
     int rc;
     if ((rc = ctx_bind(ctx))) return rc;
@@ -686,6 +709,11 @@ struct lc_pipe {
     bool has_roi = false;
     bool has_gate = false;        // colour gate in front of the gray conversion
     GateDev gate{};
+    // cv2.resize in front of everything: submitted frames are src_w x src_h, the pipeline works on width x height
+    bool resizes = false, resize_area2 = false;
+    int src_w = 0, src_h = 0;
+    size_t src_frame_bytes = 0;   // bytes of one submitted frame
+    DevBuf<int> resize_tab;
     // A pipeline owns three streams, whatever its number of slots; a slot is a set of buffers and events.
     // (HIP maps streams onto a few hardware queues.  Streams that share one see each other's event waits as
     // barriers, which at best serialises batches that should overlap and at worst ties two queues into a
@@ -723,13 +751,12 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     const int n = s.nframes;
     hipStream_t es = pp->st_edge;
     const bool hough = p.want_accumulator || p.want_segments;
-    if (!hough) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
+    const bool points = hough || p.want_points;
+    if (!points) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
                     w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p);
     (void)hipEventRecord(s.ev[EV_EDGE], es);
-    if (hough) {
-        launch_points(w.g, n, w.rowplane.p, w.rowcount.p, w.nz.p, w.nz_cap, w.npoints.p, w.r_status, es);
-    }
+    if (points) launch_points(w.g, n, w.rowplane.p, w.rowcount.p, w.nz.p, w.nz_cap, w.npoints.p, w.r_status, es);
     (void)hipEventRecord(s.ev[EV_POINTS], es);
     // The full-vote accumulator depends only on the point list.  With segments wanted, the HoughLinesP kernel
     // produces it on the side (its helper wavefronts, from the same LDS-resident set-up) and the vote kernel
@@ -793,6 +820,11 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
         HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], es));
     }
     HIP_TRY(hipEventRecord(s.ev[EV_ESTART], es));
+    if (pp->resizes) {
+        launch_resize_linear(s.input, pp->src_w, pp->src_h, 3, n, w.bgr.p, w.g.W, w.g.H, pp->resize_tab.p, pp->resize_area2, es);
+        s.input = w.bgr.p;
+        s.input_bytes = (size_t)n * 3 * w.npix;
+    }
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
                  pp->has_gate ? &pp->gate : nullptr, pp->ctx->hsv_tab.p, w.gray.p);
@@ -847,6 +879,20 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     pp->line_length = (int)lrint(p.min_line_length);
     pp->line_gap = (int)lrint(p.max_line_gap);
 
+    pp->src_w = p.src_width > 0 ? p.src_width : p.width;
+    pp->src_h = p.src_height > 0 ? p.src_height : p.height;
+    if (pp->src_w > MAX_DIM || pp->src_h > MAX_DIM) { delete pp; return fail(LC_EUNSUPPORTED, "source frames above %d pixels a side are not supported", MAX_DIM); }
+    pp->resizes = pp->src_w != p.width || pp->src_h != p.height;
+    pp->src_frame_bytes = (size_t)3 * pp->src_w * pp->src_h;
+    if (pp->resizes) {
+        const size_t tn = 2 * ((size_t)p.width + p.height);
+        std::vector<int> tab(tn);
+        pp->resize_area2 = resize_tables_host(pp->src_w, pp->src_h, p.width, p.height, tab.data(), tab.data() + p.width,
+                                              tab.data() + 2 * p.width, tab.data() + 2 * p.width + p.height);
+        if ((rc = pp->resize_tab.alloc(tn))) { delete pp; return rc; }
+        hipError_t e = hipMemcpy(pp->resize_tab.p, tab.data(), sizeof(int) * tn, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "resize table upload failed: %s", hipGetErrorString(e)); }
+    }
     if (p.hsv_gate) {
         if ((rc = ctx_hsv_tab(ctx))) { delete pp; return rc; }
         pp->has_gate = true;
@@ -900,13 +946,16 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
         }
         if ((rc = s.w.init_images(p.width, p.height, p.max_batch, true, p.keep_intermediates != 0, true))) { lc_pipe_destroy(pp); return rc; }
+        if (pp->resizes && (rc = s.w.src_in.alloc((size_t)p.max_batch * pp->src_frame_bytes))) { lc_pipe_destroy(pp); return rc; }
         // frames the streaming front kernel cannot take pass through a gated gray image
         if (pp->has_gate && !s.w.gray.p && !front_stream_supported(pp->g) &&
             (rc = s.w.gray.alloc((size_t)p.max_batch * p.width * p.height))) { lc_pipe_destroy(pp); return rc; }
-        if (hough) {
+        if (hough || p.want_points) {
             // point list capacity per frame: an eighth of the pixels (a Canny map inside an ROI stays far below)
             int cap = std::max(1024, (int)std::min<size_t>((size_t)p.width * p.height, (size_t)p.width * p.height / 8 + 1024));
             if ((rc = s.w.init_points(cap))) { lc_pipe_destroy(pp); return rc; }
+        }
+        if (hough) {
             if ((rc = s.w.init_hough(p.rho, p.theta, std::max(p.seg_capacity, 1), p.want_accumulator != 0, p.want_segments != 0, pp->st_edge))) {
                 lc_pipe_destroy(pp);
                 return rc;
@@ -952,10 +1001,11 @@ int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nf
     if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "submit: bad frames argument");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
     s->nframes = nframes;
-    s->input_bytes = (size_t)nframes * 3 * s->w.npix;
-    s->input = s->w.bgr.p;
+    s->input_bytes = (size_t)nframes * pipe->src_frame_bytes;
+    uint8_t *own = pipe->resizes ? s->w.src_in.p : s->w.bgr.p;
+    s->input = own;
     HIP_TRY(hipEventRecord(s->ev[EV_START], pipe->st_up));
-    HIP_TRY(hipMemcpyAsync(s->w.bgr.p, host_bgr, s->input_bytes, hipMemcpyHostToDevice, pipe->st_up));
+    HIP_TRY(hipMemcpyAsync(own, host_bgr, s->input_bytes, hipMemcpyHostToDevice, pipe->st_up));
     return enqueue_all(pipe, *s, true);
 }
 
@@ -967,7 +1017,7 @@ int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nfra
     if (((uintptr_t)dev_bgr & 15) != 0) return fail(LC_EINVAL, "submit: device frames must be 16-byte aligned");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
     s->nframes = nframes;
-    s->input_bytes = (size_t)nframes * 3 * s->w.npix;
+    s->input_bytes = (size_t)nframes * pipe->src_frame_bytes;
     s->input = (const uint8_t *)dev_bgr;
     return enqueue_all(pipe, *s, false);
 }
@@ -1006,13 +1056,36 @@ int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes
         case LC_BUF_MASKED: src = w.masked.p; need = img; break;
         case LC_BUF_ACC: src = pipe->p.want_accumulator ? w.acc_full.p : nullptr;
             need = sizeof(int32_t) * (size_t)s->nframes * w.hg.numangle * w.hg.numrho; break;
-        case LC_BUF_NPOINTS: src = (pipe->p.want_accumulator || pipe->p.want_segments) ? w.npoints.p : nullptr;
+        case LC_BUF_NPOINTS: src = (pipe->p.want_accumulator || pipe->p.want_segments || pipe->p.want_points) ? w.npoints.p : nullptr;
             need = sizeof(int) * s->nframes; break;
+        case LC_BUF_RESIZED: src = pipe->resizes ? w.bgr.p : nullptr; need = 3 * img; break;
         default: return fail(LC_EINVAL, "unknown buffer id %d", what);
     }
     if (!src) return fail(LC_EINVAL, "buffer %d is not produced by this pipeline's configuration", what);
     if (bytes < need) return fail(LC_ECAP, "destination holds %zu bytes, %zu needed", bytes, need);
     HIP_TRY(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    return LC_OK;
+}
+
+int lc_pipe_read_points(lc_pipe *pipe, int slot, int frame, uint32_t *xy, int capacity, int *n) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (s->busy) return fail(LC_EINVAL, "slot %d has not been waited for", slot);
+    if (!n) return fail(LC_EINVAL, "null count pointer");
+    if (!(pipe->p.want_accumulator || pipe->p.want_segments || pipe->p.want_points))
+        return fail(LC_EINVAL, "this pipeline's configuration does not produce the point list");
+    if (frame < 0 || frame >= s->nframes) return fail(LC_EINVAL, "frame %d out of range [0, %d)", frame, s->nframes);
+    Work &w = s->w;
+    int np = 0;
+    HIP_TRY(hipMemcpy(&np, w.npoints.p + frame, sizeof(int), hipMemcpyDeviceToHost));
+    *n = np;
+    if (np > w.nz_cap) return fail(LC_ECAP, "frame %d has %d edge points, the slot keeps %d", frame, np, w.nz_cap);
+    if (np > capacity) return fail(LC_ECAP, "frame %d has %d edge points, destination holds %d", frame, np, capacity);
+    if (np > 0) {
+        if (!xy) return fail(LC_EINVAL, "null destination");
+        HIP_TRY(hipMemcpy(xy, w.nz.p + (size_t)frame * w.nz_cap, sizeof(uint32_t) * np, hipMemcpyDeviceToHost));
+    }
     return LC_OK;
 }
 
@@ -1060,7 +1133,8 @@ int lc_pipe_upload(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "upload: bad frames argument");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
-    HIP_TRY(hipMemcpyAsync(s->w.bgr.p, host_bgr, (size_t)nframes * 3 * s->w.npix, hipMemcpyHostToDevice, pipe->st_up));
+    HIP_TRY(hipMemcpyAsync(pipe->resizes ? s->w.src_in.p : s->w.bgr.p, host_bgr, (size_t)nframes * pipe->src_frame_bytes,
+                           hipMemcpyHostToDevice, pipe->st_up));
     HIP_TRY(hipStreamSynchronize(pipe->st_up));
     return LC_OK;
 }
@@ -1070,7 +1144,7 @@ int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr) {
     int rc;
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!dev_ptr) return fail(LC_EINVAL, "null output");
-    *dev_ptr = s->w.bgr.p;
+    *dev_ptr = pipe->resizes ? s->w.src_in.p : s->w.bgr.p;
     return LC_OK;
 }
 

@@ -46,7 +46,14 @@ GateDev make_gate(const int *bounds, int nboxes);
 // the two reciprocal tables of the HSV conversion, sdiv[256] then hdiv[256]
 void hsv_tables_host(int *tab512);
 
+// cv::resize INTER_LINEAR tables for (sw, sh) -> (dw, dh): xofs[dw], ia[dw], yofs[dh], ib[dh] (weights packed
+// a0 | a1 << 16); returns true when the size pair is the exact 2x2 decimation OpenCV reroutes to its area code
+bool resize_tables_host(int sw, int sh, int dw, int dh, int *xofs, int *ia, int *yofs, int *ib);
+
 // ---- launchers (each enqueues on `st`; no synchronisation inside) ----------
+// dense frames [n][sh][sw][cn] -> [n][dh][dw][cn]; tabs = the four tables back to back in device memory
+void launch_resize_linear(const uint8_t *src, int sw, int sh, int cn, int nframes, uint8_t *dst, int dw, int dh,
+                          const int *tabs, bool area2, hipStream_t st);
 // colour gate (kernels_gate.hip); tab = device copy of hsv_tables_host
 void launch_hsv(const uint8_t *src, size_t npix, int code, const int *tab, uint8_t *dst, hipStream_t st);
 void launch_in_range3(const uint8_t *src, size_t npix, GateDev box0, uint8_t *dst, hipStream_t st);

@@ -71,6 +71,34 @@ __global__ __launch_bounds__(256) void k_gate_gray(const uint8_t *__restrict__ s
     }
 }
 
+// cv::resize, INTER_LINEAR, 8-bit, cn = 1 or 3 interleaved channels, dense frames.  One thread per output
+// pixel.  The host builds OpenCV's tables: per output column the left source column and the two 11-bit
+// weights (a0 | a1 << 16), per output row the upper source row (unclipped) and its two weights.
+//   H = S[sx] * a0 + S[sx + 1] * a1;   D = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2
+// area2: exact 2x2 decimation, which OpenCV reroutes to its area code: D = (sum of the four + 2) >> 2.
+__global__ __launch_bounds__(256) void k_resize_linear(const uint8_t *__restrict__ src, int sw, int sh, int cn,
+                                                       uint8_t *__restrict__ dst, int dw, int dh,
+                                                       const int *__restrict__ xofs, const int *__restrict__ ia,
+                                                       const int *__restrict__ yofs, const int *__restrict__ ib, int area2) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, f = blockIdx.z;
+    if (dx >= dw) return;
+    const uint8_t *fs = src + (size_t)f * sw * sh * cn;
+    uint8_t *out = dst + ((size_t)f * dh + dy) * (size_t)dw * cn + (size_t)dx * cn;
+    if (area2) {
+        const uint8_t *s0 = fs + ((size_t)(2 * dy) * sw + 2 * dx) * cn, *s1 = s0 + (size_t)sw * cn;
+        for (int c = 0; c < cn; c++) out[c] = (uint8_t)((s0[c] + s0[cn + c] + s1[c] + s1[cn + c] + 2) >> 2);
+        return;
+    }
+    const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1), a = ia[dx], a0 = (short)(a & 0xFFFF), a1 = a >> 16;
+    const int sy = yofs[dy], b = ib[dy], b0 = (short)(b & 0xFFFF), b1 = b >> 16;
+    const uint8_t *r0 = fs + (size_t)min(max(sy, 0), sh - 1) * sw * cn, *r1 = fs + (size_t)min(max(sy + 1, 0), sh - 1) * sw * cn;
+    for (int c = 0; c < cn; c++) {
+        const int h0 = r0[sx * cn + c] * a0 + r0[sx1 * cn + c] * a1;
+        const int h1 = r1[sx * cn + c] * a0 + r1[sx1 * cn + c] * a1;
+        out[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -97,6 +125,38 @@ GateDev make_gate(const int *b, int nboxes) {
             g.span[3 * box + c] = (uint32_t)(hi - lo);
         }
     return g;
+}
+
+bool resize_tables_host(int sw, int sh, int dw, int dh, int *xofs, int *ia, int *yofs, int *ib) {
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    const int iscale_x = (int)std::lrint(scale_x), iscale_y = (int)std::lrint(scale_y);
+    const bool area2 = std::fabs(scale_x - iscale_x) < 2.220446049250313e-16 && std::fabs(scale_y - iscale_y) < 2.220446049250313e-16 &&
+                       iscale_x == 2 && iscale_y == 2;
+    auto sat_short = [](float v) { long r = std::lrintf(v); return (int)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r)); };
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ia[dx] = (sat_short((1.f - fx) * 2048) & 0xFFFF) | (sat_short(fx * 2048) << 16);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)std::floor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ib[dy] = (sat_short((1.f - fy) * 2048) & 0xFFFF) | (sat_short(fy * 2048) << 16);
+    }
+    return area2;
+}
+
+void launch_resize_linear(const uint8_t *src, int sw, int sh, int cn, int nframes, uint8_t *dst, int dw, int dh,
+                          const int *tabs, bool area2, hipStream_t st) {
+    // tabs: xofs[dw], ia[dw], yofs[dh], ib[dh] back to back
+    hipLaunchKernelGGL(k_resize_linear, dim3((dw + 255) / 256, dh, nframes), dim3(256), 0, st, src, sw, sh, cn, dst, dw, dh, tabs,
+                       tabs + dw, tabs + 2 * dw, tabs + 2 * dw + dh, area2 ? 1 : 0);
 }
 
 void launch_hsv(const uint8_t *src, size_t npix, int code, const int *tab, uint8_t *dst, hipStream_t st) {

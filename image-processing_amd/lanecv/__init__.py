@@ -5,7 +5,7 @@ OpenCV_*.py` scripts and `LaneTracker.detect_and_draw` of `F1_vo_Lane_Tracking.p
 source-compatible for these calls:
 
     cvtColor (COLOR_BGR2GRAY / COLOR_RGB2GRAY / COLOR_BGR2HSV / COLOR_RGB2HSV),
-    GaussianBlur ((5,5), sigma 0), Canny (aperture 3, L1), fillPoly (LINE_8, shift 0),
+    resize (INTER_LINEAR, explicit dsize), GaussianBlur ((5,5), sigma 0), Canny (aperture 3, L1), fillPoly (LINE_8, shift 0),
     rectangle (filled), inRange (8UC3, integer bounds), bitwise_or, bitwise_and (optional mask),
     HoughLinesP
 
@@ -23,13 +23,14 @@ import numpy as _np
 from . import _abi
 from ._abi import error
 
-__all__ = ["cvtColor", "GaussianBlur", "Canny", "fillPoly", "rectangle", "inRange", "bitwise_or", "bitwise_and",
+__all__ = ["cvtColor", "resize", "GaussianBlur", "Canny", "fillPoly", "rectangle", "inRange", "bitwise_or", "bitwise_and",
            "HoughLinesP", "hough_accumulator", "error"]
 
 COLOR_BGR2GRAY = 6
 COLOR_RGB2GRAY = 7
 COLOR_BGR2HSV = 40
 COLOR_RGB2HSV = 41
+INTER_LINEAR = 1
 BORDER_REPLICATE = 1
 BORDER_REFLECT_101 = 4
 BORDER_REFLECT101 = 4
@@ -93,6 +94,28 @@ def cvtColor(src, code, dst=None, dstCn=0):
         raise error("cvtColor: dstCn must be 0 or 1 for a gray destination")
     out = _dst(dst, (h, w))
     _abi.check(_abi.lib().lc_cvt_gray(_abi.context(), _abi.ptr(s), w, h, stride, int(code), _abi.ptr(out), w))
+    return out
+
+
+def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
+    """cv2.resize(src, (width, height)) with INTER_LINEAR on an 8-bit image of 1 or 3 channels.
+    Reference: F1_vo_Lane_Tracking.py:185."""
+    if not isinstance(src, _np.ndarray) or src.ndim not in (2, 3):
+        raise error("resize: src must be a 2- or 3-dimensional numpy array")
+    src = _image(src, "src", src.ndim)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    if cn not in (1, 3):
+        raise error("resize: 1 or 3 channels are supported, got %d" % cn, _abi.LC_EUNSUPPORTED)
+    if interpolation != INTER_LINEAR:
+        raise error("resize: only INTER_LINEAR is supported", _abi.LC_EUNSUPPORTED)
+    if dsize is None or len(dsize) != 2 or int(dsize[0]) <= 0 or int(dsize[1]) <= 0 or fx or fy:
+        raise error("resize: an explicit positive dsize (width, height) is required; fx / fy are not supported",
+                    _abi.LC_EUNSUPPORTED)
+    dw, dh = int(dsize[0]), int(dsize[1])
+    s, stride = _rows(src)
+    sh, sw = s.shape[:2]
+    out = _dst(dst, (dh, dw) if src.ndim == 2 else (dh, dw, cn))
+    _abi.check(_abi.lib().lc_resize_linear(_abi.context(), _abi.ptr(s), sw, sh, stride, cn, _abi.ptr(out), dw, dh, dw * cn))
     return out
 
 

@@ -20,16 +20,16 @@ class error(Exception):
 
 LC_OK, LC_EINVAL, LC_ENOMEM, LC_ECAP, LC_EHIP, LC_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
-BUF_GRAY, BUF_BLUR, BUF_EDGES, BUF_MASKED, BUF_ACC, BUF_NPOINTS = 1, 2, 3, 4, 5, 6
+BUF_GRAY, BUF_BLUR, BUF_EDGES, BUF_MASKED, BUF_ACC, BUF_NPOINTS, BUF_RESIZED = 1, 2, 3, 4, 5, 6, 7
 STAGE_UPLOAD, STAGE_EDGE, STAGE_POINTS, STAGE_VOTE, STAGE_LINES, STAGE_TOTAL, STAGE_FRONT, STAGE_HYST, STAGE_FINAL = range(9)
 
 # every symbol include/lanecv.h declares
 SYMBOLS = [
     "lc_version", "lc_last_error", "lc_create", "lc_destroy", "lc_host_alloc_pinned", "lc_host_free",
-    "lc_cvt_gray", "lc_cvt_hsv", "lc_in_range3", "lc_or", "lc_and3_mask", "lc_gaussian5", "lc_canny", "lc_fill_poly", "lc_rectangle_filled", "lc_and",
+    "lc_cvt_gray", "lc_cvt_hsv", "lc_in_range3", "lc_or", "lc_and3_mask", "lc_resize_linear", "lc_gaussian5", "lc_canny", "lc_fill_poly", "lc_rectangle_filled", "lc_and",
     "lc_hough_geometry", "lc_hough_accum", "lc_hough_lines_p",
     "lc_pipe_create", "lc_pipe_destroy", "lc_pipe_submit_host", "lc_pipe_submit_device", "lc_pipe_wait",
-    "lc_pipe_read", "lc_pipe_stage_ms", "lc_pipe_input_device_ptr", "lc_pipe_upload", "lc_pipe_hyst_rounds",
+    "lc_pipe_read", "lc_pipe_read_points", "lc_pipe_stage_ms", "lc_pipe_input_device_ptr", "lc_pipe_upload", "lc_pipe_hyst_rounds",
 ]
 
 
@@ -43,7 +43,7 @@ class PipeParams(C.Structure):
         ("min_line_length", C.c_double), ("max_line_gap", C.c_double),
         ("seg_capacity", C.c_int), ("want_accumulator", C.c_int), ("want_segments", C.c_int),
         ("keep_intermediates", C.c_int),
-        ("hsv_gate", C.c_int), ("hsv_bounds", C.c_int * 12),
+        ("hsv_gate", C.c_int), ("hsv_bounds", C.c_int * 12), ("want_points", C.c_int), ("src_width", C.c_int), ("src_height", C.c_int),
     ]
 
 
@@ -68,6 +68,7 @@ def lib():
         L.lc_in_range3.argtypes = [vp, vp, i, i, sz, C.POINTER(i), C.POINTER(i), vp, sz]
         L.lc_or.argtypes = [vp, vp, sz, vp, sz, vp, sz, i, i]
         L.lc_and3_mask.argtypes = [vp, vp, sz, vp, sz, vp, sz, i, i]
+        L.lc_resize_linear.argtypes = [vp, vp, i, i, sz, i, vp, i, i, sz]
         L.lc_gaussian5.argtypes = [vp, vp, i, i, sz, vp, sz]
         L.lc_canny.argtypes = [vp, vp, i, i, sz, d, d, vp, sz]
         L.lc_fill_poly.argtypes = [vp, vp, i, i, sz, vp, vp, i, i]
@@ -82,6 +83,7 @@ def lib():
         L.lc_pipe_submit_device.argtypes = [vp, i, vp, i]
         L.lc_pipe_wait.argtypes = [vp, i, vp, vp]
         L.lc_pipe_read.argtypes = [vp, i, i, vp, sz]
+        L.lc_pipe_read_points.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
         L.lc_pipe_stage_ms.argtypes = [vp, i, i, C.POINTER(C.c_float)]
         L.lc_pipe_input_device_ptr.argtypes = [vp, i, C.POINTER(vp)]
         L.lc_pipe_upload.argtypes = [vp, i, vp, i]

@@ -11,11 +11,15 @@ reference's post-Hough blocks and keeps its observable quirks:
   the routine the scripts call), evaluated at the bottom row and at 3/5 of the height and truncated with
   ``int()`` (`..._2(images).py:116-143`);
 * the video scripts smooth over frames with alpha = 0.1: `..._4(mp4).py:144-178` averages the four integers of
-  each lane line (truncating again), `..._5(mp4).py:108-138` the three coefficients of a degree-2 fit.
+  each lane line (truncating again), `..._5(mp4).py:108-138` the three coefficients of a degree-2 fit;
+* the F1 tracker works on edge pixels, not segments (`F1_vo_Lane_Tracking.py:114-132`, `:42-91`): the non-zero
+  pixels of the masked edge map split at the middle column, a degree-2 fit x(y) per side when more than 50
+  pixels are there, blended with the previous fit as ``0.7 * previous + 0.3 * new``, and sampled at every row
+  into the int32 polyline the script draws.
 """
 import numpy as np
 
-__all__ = ["split_by_slope", "lane_lines", "LineSmoother", "CurveSmoother"]
+__all__ = ["split_by_slope", "lane_lines", "LineSmoother", "CurveSmoother", "split_at_midpoint", "PixelCurveTracker"]
 
 
 def split_by_slope(lines, min_abs_slope=0.5):
@@ -114,3 +118,50 @@ class CurveSmoother:
         self.left = self._blend(self.left, self._fit(lx, ly))
         self.right = self._blend(self.right, self._fit(rx, ry))
         return self.left, self.right
+
+
+def split_at_midpoint(nonzeroy, nonzerox, width):
+    """`F1_vo_Lane_Tracking.py:116-129`: ``(leftx, lefty, rightx, righty)`` with left = columns below
+    ``width // 2``; the pixel order (row-major) is kept."""
+    nonzeroy, nonzerox = np.asarray(nonzeroy), np.asarray(nonzerox)
+    midpoint = width // 2
+    left = nonzerox < midpoint
+    right = nonzerox >= midpoint
+    return nonzerox[left], nonzeroy[left], nonzerox[right], nonzeroy[right]
+
+
+class PixelCurveTracker:
+    """`LaneTracker.fit_poly` (`F1_vo_Lane_Tracking.py:33-91`): per side a degree-2 fit x(y) through the edge
+    pixels with memory.  A side with at most `min_points` pixels, or a fit that raises TypeError, reuses the
+    previous coefficients; a side never fitted yields None."""
+
+    def __init__(self, alpha=0.7, min_points=50):
+        self.alpha, self.min_points = alpha, min_points
+        self.prev_left_fit = None
+        self.prev_right_fit = None
+
+    def _side(self, xs, ys, prev):
+        if len(ys) > self.min_points:
+            try:
+                fit = np.polyfit(ys, xs, 2)
+                if prev is not None:
+                    fit = self.alpha * prev + (1 - self.alpha) * fit
+                return fit, fit
+            except TypeError:
+                return prev, prev
+        return prev, prev
+
+    @staticmethod
+    def _curve(fit, ploty):
+        if fit is None:
+            return None
+        fitx = fit[0] * ploty ** 2 + fit[1] * ploty + fit[2]
+        return np.array([np.transpose(np.vstack([fitx, ploty]))]).astype(np.int32)
+
+    def fit_poly(self, shape, leftx, lefty, rightx, righty):
+        """Returns ``(left_curve, right_curve)``: int32 arrays of shape (1, height, 2) holding (x, y) per row,
+        or None for a side without a fit so far."""
+        ploty = np.linspace(0, shape[0] - 1, shape[0])
+        left_fit, self.prev_left_fit = self._side(leftx, lefty, self.prev_left_fit)
+        right_fit, self.prev_right_fit = self._side(rightx, righty, self.prev_right_fit)
+        return self._curve(left_fit, ploty), self._curve(right_fit, ploty)

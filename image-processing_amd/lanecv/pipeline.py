@@ -67,6 +67,7 @@ class Recipe:
     # colour gate in front of the gray conversion: (lo0, hi0, lo1, hi1), each an (H, S, V) triple of the two
     # inRange calls whose masks are ORed, or None
     hsv_gate: Optional[tuple] = None
+    points: bool = False      # keep the ordered edge-point list (what masked_edges.nonzero() enumerates)
 
     @staticmethod
     def simple(w, h, threshold=160, max_line_gap=25):
@@ -91,7 +92,7 @@ class Recipe:
     def f1(w, h):
         """`F1_vo_Lane_Tracking.py:97-112`: blur, Canny(50,150), car mask, trapezoid; no Hough."""
         return Recipe(color_code=6, blur=True, canny=(50, 150), roi_vertices=trapezoid_roi(w, h),
-                      car_mask=f1_car_mask(w, h), segments=False, accumulator=False)
+                      car_mask=f1_car_mask(w, h), segments=False, accumulator=False, points=True)
 
     @staticmethod
     def north_star(w, h):
@@ -101,9 +102,12 @@ class Recipe:
 
 class LanePipeline:
     def __init__(self, width, height, recipe, max_batch=32, nslots=2, seg_capacity=128,
-                 keep_intermediates=False, device=None):
+                 keep_intermediates=False, device=None, src_size=None):
+        """src_size = (width, height) of the submitted frames when they differ from the pipeline's size: the
+        pipeline then starts with ``cv2.resize(frame, (width, height))`` (`F1_vo_Lane_Tracking.py:185`)."""
         import lanecv as cv2
         self.w, self.h, self.recipe = int(width), int(height), recipe
+        self.sw, self.sh = (int(src_size[0]), int(src_size[1])) if src_size is not None else (self.w, self.h)
         self.max_batch, self.nslots, self.seg_capacity = int(max_batch), int(nslots), int(seg_capacity)
         self.keep = bool(keep_intermediates)
         self.roi = None
@@ -125,6 +129,8 @@ class LanePipeline:
             min_line_length=float(recipe.min_line_length), max_line_gap=float(recipe.max_line_gap),
             seg_capacity=self.seg_capacity, want_accumulator=int(bool(recipe.accumulator)),
             want_segments=int(bool(recipe.segments)), keep_intermediates=int(self.keep))
+        p.want_points = int(bool(recipe.points))
+        p.src_width, p.src_height = self.sw, self.sh
         if recipe.hsv_gate is not None:
             flat = [int(v) for box in recipe.hsv_gate for v in box]
             if len(flat) != 12:
@@ -151,18 +157,18 @@ class LanePipeline:
         """A page-locked (n, h, w, 3) uint8 array for overlapped uploads; freed with the process."""
         n = self.max_batch if n is None else n
         p = C.c_void_p()
-        nbytes = n * self.h * self.w * 3
+        nbytes = n * self.sh * self.sw * 3
         _abi.check(_abi.lib().lc_host_alloc_pinned(nbytes, C.byref(p)))
         buf = (C.c_uint8 * nbytes).from_address(p.value)
-        return np.frombuffer(buf, np.uint8).reshape(n, self.h, self.w, 3)
+        return np.frombuffer(buf, np.uint8).reshape(n, self.sh, self.sw, 3)
 
     def submit(self, slot, frames):
         frames = np.asarray(frames)
         if frames.ndim == 3:
             frames = frames[None]
-        if frames.dtype != np.uint8 or frames.shape[1:] != (self.h, self.w, 3):
+        if frames.dtype != np.uint8 or frames.shape[1:] != (self.sh, self.sw, 3):
             raise error("submit: expected uint8 frames of shape (n, %d, %d, 3), got %s %s"
-                        % (self.h, self.w, frames.dtype, frames.shape))
+                        % (self.sh, self.sw, frames.dtype, frames.shape))
         frames = np.ascontiguousarray(frames)
         _abi.check(_abi.lib().lc_pipe_submit_host(self._h, slot, _abi.ptr(frames), len(frames)))
         self._n[slot] = len(frames)
@@ -172,8 +178,8 @@ class LanePipeline:
         """Copies frames into the slot's own HBM input buffer (synchronous) and returns its device pointer;
         `submit_device(slot, ptr, n)` then runs with the input already resident."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
-        if frames.shape[1:] != (self.h, self.w, 3):
-            raise error("upload: expected frames of shape (n, %d, %d, 3), got %s" % (self.h, self.w, frames.shape))
+        if frames.shape[1:] != (self.sh, self.sw, 3):
+            raise error("upload: expected frames of shape (n, %d, %d, 3), got %s" % (self.sh, self.sw, frames.shape))
         _abi.check(_abi.lib().lc_pipe_upload(self._h, slot, _abi.ptr(frames), len(frames)))
         p = C.c_void_p()
         _abi.check(_abi.lib().lc_pipe_input_device_ptr(self._h, slot, C.byref(p)))
@@ -213,9 +219,24 @@ class LanePipeline:
             out = np.empty((n, self.numangle, self.numrho), np.int32)
         elif what == _abi.BUF_NPOINTS:
             out = np.empty(n, np.int32)
+        elif what == _abi.BUF_RESIZED:
+            out = np.empty((n, self.h, self.w, 3), np.uint8)
         else:
             out = np.empty((n, self.h, self.w), np.uint8)
         _abi.check(_abi.lib().lc_pipe_read(self._h, slot, what, _abi.ptr(out), out.nbytes))
+        return out
+
+    def nonzero(self, slot):
+        """Per frame ``(ys, xs)`` of the masked edge map's non-zero pixels in row-major order -- the arrays
+        ``masked_edges.nonzero()`` returns at `F1_vo_Lane_Tracking.py:117-119` -- from the device's point list."""
+        counts = self.read(slot, _abi.BUF_NPOINTS)
+        out = []
+        for i, c in enumerate(counts):
+            xy = np.empty(max(int(c), 1), np.uint32)
+            n = C.c_int()
+            _abi.check(_abi.lib().lc_pipe_read_points(self._h, slot, i, _abi.ptr(xy), len(xy), C.byref(n)))
+            xy = xy[:n.value]
+            out.append(((xy >> 16).astype(np.int64), (xy & 0xFFFF).astype(np.int64)))
         return out
 
     def hyst_rounds(self, slot):

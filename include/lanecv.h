@@ -82,6 +82,12 @@ int lc_or(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size
 int lc_and3_mask(lc_ctx *ctx, const uint8_t *src, size_t src_stride, const uint8_t *mask, size_t mask_stride,
                  uint8_t *dst, size_t dst_stride, int w, int h);
 
+/* cv2.resize(src, (dw, dh)) with the default INTER_LINEAR on an 8-bit image of 1 or 3 channels
+ * (OpenCV's 11-bit fixed-point bilinear; an exact 2x2 decimation takes its area average instead).
+ * Replaces: F1_vo_Lane_Tracking.py:185. */
+int lc_resize_linear(lc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, int channels,
+                     uint8_t *dst, int dw, int dh, size_t dst_stride);
+
 /* cv2.GaussianBlur(src, (5,5), 0), 8UC1, BORDER_REFLECT_101.
  * Replaces: F1_vo_Lane_Tracking.py:97. */
 int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
@@ -156,6 +162,10 @@ typedef struct lc_pipe_params {
      * gray = cvtColor(bitwise_and(frame, frame, mask=m), color_code).  LC_BUF_GRAY is that gated gray. */
     int hsv_gate;             /* 1: apply the gate */
     int hsv_bounds[12];       /* lo0[3], hi0[3], lo1[3], hi1[3], each in H, S, V order */
+    int want_points;          /* keep the ordered list of edge points even without a Hough stage (lc_pipe_read_points) */
+    /* cv2.resize(frame, (width, height)) in front of the recipe (F1_vo_Lane_Tracking.py:185): submitted frames
+     * are src_width x src_height; 0 = the pipeline's own size, no resize. */
+    int src_width, src_height;
 } lc_pipe_params;
 
 /* What lc_pipe_read copies out of a finished slot. */
@@ -165,6 +175,7 @@ typedef struct lc_pipe_params {
 #define LC_BUF_MASKED   4     /* uint8  [n][h][w]   edge map after car mask and ROI */
 #define LC_BUF_ACC      5     /* int32  [n][numangle][numrho] (want_accumulator) */
 #define LC_BUF_NPOINTS  6     /* int32  [n]         non-zero pixels of the masked edge map */
+#define LC_BUF_RESIZED  7     /* uint8  [n][h][w][3] the frames after the leading resize (src_width / src_height set) */
 
 /* Stages timed with HIP events on the slot's stream (lc_pipe_stage_ms). */
 #define LC_STAGE_UPLOAD 0
@@ -192,6 +203,12 @@ int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nfra
  * A frame with more than seg_capacity segments reports its true count. */
 int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count);
 int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes);
+/* The non-zero pixels of one frame's masked edge map in row-major order, as x | y << 16 -- what
+ * masked_edges.nonzero() enumerates (F1_vo_Lane_Tracking.py:117-119).  The pipeline must have been
+ * configured with want_points, want_accumulator or want_segments (with want_segments, call it before the
+ * frame's HoughLinesP fallback could have permuted the list: it is exact whenever the status is clean).
+ * *n receives the count; LC_ECAP if it exceeds `capacity`. */
+int lc_pipe_read_points(lc_pipe *pipe, int slot, int frame, uint32_t *xy, int capacity, int *n);
 int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms);
 /* Device pointer of a slot's own input buffer (for callers that fill it on the device). */
 int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr);

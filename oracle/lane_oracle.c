@@ -844,6 +844,80 @@ done:
 }
 
 /* ------------------------------------------------------------------ */
+/* cv::resize(src, dsize) with INTER_LINEAR on 8U, 1 or 3 channels       */
+/* (imgproc/src/resize.cpp, generic path, no IPP):                       */
+/*   scale = 1 / ((double)dsize / ssize)                                 */
+/*   exact 2x2 decimation is rerouted to INTER_AREA (fast):              */
+/*       D = (S00 + S01 + S10 + S11 + 2) >> 2                            */
+/*   otherwise fixed point with INTER_RESIZE_COEF_BITS = 11:             */
+/*       fx = (float)((dx + 0.5) * scale_x - 0.5); sx = floor(fx); fx -= sx */
+/*       sx < 0 -> (sx, fx) = (0, 0); sx >= sw - 1 -> (sw - 1, 0)        */
+/*       alpha = (short)cvRound((1.f - fx) * 2048), (short)cvRound(fx * 2048) */
+/*       rows: fy, sy likewise but the two source rows are clipped to    */
+/*       [0, sh - 1] instead of changing the weights                     */
+/*       horizontal: H = S[sx] * a0 + S[sx + 1] * a1  (int)              */
+/*       vertical:   D = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2 */
+/* ------------------------------------------------------------------ */
+static int lo_clipi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static short lo_sat_short(float v) { int r = cv_round_f(v); return (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r)); }
+
+int lo_resize_linear(const uint8_t *src, int sw, int sh, long sstride, int cn,
+                     uint8_t *dst, int dw, int dh, long dstride)
+{
+    if (!src || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || (cn != 1 && cn != 3)) return LO_EINVAL;
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    const int area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    if (area_fast && iscale_x == 2 && iscale_y == 2) {
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < cn; c++) {
+                    const uint8_t *s0 = src + (2 * y) * sstride + (2 * x) * cn + c, *s1 = s0 + sstride;
+                    dst[y * dstride + x * cn + c] = (uint8_t)((s0[0] + s0[cn] + s1[0] + s1[cn] + 2) >> 2);
+                }
+        return LO_OK;
+    }
+    int *xofs = (int *)malloc(sizeof(int) * dw), *yofs = (int *)malloc(sizeof(int) * dh);
+    short *ia = (short *)malloc(sizeof(short) * 2 * dw), *ib = (short *)malloc(sizeof(short) * 2 * dh);
+    if (!xofs || !yofs || !ia || !ib) { free(xofs); free(yofs); free(ia); free(ib); return LO_ENOMEM; }
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ia[2 * dx] = lo_sat_short((1.f - fx) * 2048);
+        ia[2 * dx + 1] = lo_sat_short(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ib[2 * dy] = lo_sat_short((1.f - fy) * 2048);
+        ib[2 * dy + 1] = lo_sat_short(fy * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        const uint8_t *r0 = src + lo_clipi(yofs[dy], 0, sh - 1) * sstride;
+        const uint8_t *r1 = src + lo_clipi(yofs[dy] + 1, 0, sh - 1) * sstride;
+        const int b0 = ib[2 * dy], b1 = ib[2 * dy + 1];
+        for (int dx = 0; dx < dw; dx++) {
+            const int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sx;   /* weight of sx1 is 0 when it would fall outside */
+            const int a0 = ia[2 * dx], a1 = ia[2 * dx + 1];
+            for (int c = 0; c < cn; c++) {
+                const int h0 = r0[sx * cn + c] * a0 + r0[sx1 * cn + c] * a1;
+                const int h1 = r1[sx * cn + c] * a0 + r1[sx1 * cn + c] * a1;
+                dst[dy * dstride + dx * cn + c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+    free(xofs); free(yofs); free(ia); free(ib);
+    return LO_OK;
+}
+
+/* ------------------------------------------------------------------ */
 /* One frame through a recipe (the reference's call sequence), for the  */
 /* parity tests and the CPU baseline timing.                           */
 /*   code      LO_COLOR_*                                              */

@@ -157,6 +157,18 @@ def gate_gray(bgr, gate, gray_code=COLOR_BGR2GRAY):
     return out
 
 
+def resize_linear(img, dsize):
+    """cv2.resize(img, dsize) with INTER_LINEAR on an 8-bit image of 1 or 3 channels; dsize = (width, height)."""
+    img, p = _u8(img)
+    sh, sw = img.shape[:2]
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    dw, dh = int(dsize[0]), int(dsize[1])
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+    _chk(lib().lo_resize_linear(p, sw, sh, C.c_long(sw * cn), cn, out.ctypes.data_as(C.c_void_p), dw, dh, C.c_long(dw * cn)),
+         "resize_linear")
+    return out
+
+
 def fill_poly(img, contours, color):
     """In place, like cv2.fillPoly.  contours: list of (N,2) integer arrays."""
     assert img.dtype == np.uint8 and img.ndim == 2 and img.flags.c_contiguous

@@ -111,3 +111,37 @@ def test_curve_smoother_blends_coefficients():
             assert (got[side] is None) == (prev[side] is None)
             if prev[side] is not None:
                 assert np.array_equal(got[side], prev[side])
+
+
+def test_pixel_curve_tracker_follows_the_f1_script():
+    """`LaneTracker.fit_poly` restated line by line (F1_vo_Lane_Tracking.py:42-91) against the class."""
+    from lanecv.glue import PixelCurveTracker, split_at_midpoint
+    rng = np.random.default_rng(5)
+    h, w = 360, 640
+    trk = PixelCurveTracker()
+    prev_l = prev_r = None
+    for frame in range(4):
+        n = [300, 40, 500, 0][frame]                     # frame 1: too few pixels, frame 3: none at all
+        ys = np.sort(rng.integers(150, h, n))
+        xs = np.where(rng.random(n) < 0.5, 200 + (ys - 150) // 3, 450 - (ys - 150) // 4) + rng.integers(-2, 3, n)
+        lx, ly, rx, ry = split_at_midpoint(ys, xs, w)
+        assert (lx < w // 2).all() and (rx >= w // 2).all() and len(lx) + len(rx) == n
+        got_l, got_r = trk.fit_poly((h, w), lx, ly, rx, ry)
+        ploty = np.linspace(0, h - 1, h)
+        want = []
+        for x_, y_, prev in ((lx, ly, prev_l), (rx, ry, prev_r)):
+            fit = prev
+            if len(y_) > 50:
+                fit = np.polyfit(y_, x_, 2)
+                if prev is not None:
+                    fit = 0.7 * prev + (1 - 0.7) * fit
+            want.append(fit)
+        prev_l, prev_r = want
+        for got, fit in ((got_l, prev_l), (got_r, prev_r)):
+            if fit is None:
+                assert got is None
+            else:
+                fx = fit[0] * ploty ** 2 + fit[1] * ploty + fit[2]
+                assert got.dtype == np.int32 and got.shape == (1, h, 2)
+                assert (got[0, :, 0] == fx.astype(np.int32)).all() and (got[0, :, 1] == np.arange(h)).all()
+    assert prev_l is not None and prev_r is not None
