@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     // three-row windows, slot = phase of the iteration that wrote it
     Pair Hh[3] = {}, Tt[3] = {};                   // horizontal blur sums (+8), first vertical [1 2 1] pass
     Pair Dw[3] = {}, Sw[3] = {};                   // Sobel partial sums of the Sobel input rows
-    Pair Mw[3] = {}, Nw[3] = {};                   // magnitudes; Nw.e = left neighbours of the e pixels, Nw.o = right neighbours of the o pixels
+    Pair Mw[3] = {};                               // magnitudes
     Pair DXw[3] = {}, DYw[3] = {};                 // gradients
 
     uint32_t L[3][3] = {};                         // source rows of a group: consumed by the gray conversion at the
@@ -268,8 +268,6 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             Mw[P].o = pkadd(pkabs(DXw[P].o), pkabs(DYw[P].o));
             if (m_row < 0 || m_row >= H) { asm volatile(""); Mw[P].e = 0u; Mw[P].o = 0u; }
             else if (has_border) { Mw[P].e = inimg ? Mw[P].e : 0u; Mw[P].o = inimg ? Mw[P].o : 0u; }
-            Nw[P].e = alignbyte(Mw[P].o, from_left(Mw[P].o), 2);
-            Nw[P].o = alignbyte(from_right(Mw[P].e), Mw[P].e, 2);
         }
 
         // ---- non-maximum suppression + thresholds of row n = m - 1 -----------------------------
@@ -300,6 +298,14 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
                     sbit = pknz(strong);
                     wbit = pknz(keep) ^ sbit;
                 };
+                // magnitudes of the neighbouring lanes' pixels, for the three rows: .e = left neighbours of the e
+                // pixels (px-1, px1), .o = right neighbours of the o pixels (px2, px4)
+                Pair Nw[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    Nw[k].e = alignbyte(Mw[k].o, from_left(Mw[k].o), 2);
+                    Nw[k].o = alignbyte(from_right(Mw[k].e), Mw[k].e, 2);
+                }
                 uint32_t se, we, so, wo;
                 nms(ce, DXw[PREV].e, DYw[PREV].e, Nw[PREV].e, co, Nw[OLD].e, Mw[OLD].e, Mw[OLD].o, Nw[P].e, Mw[P].e, Mw[P].o, se, we);
                 nms(co, DXw[PREV].o, DYw[PREV].o, ce, Nw[PREV].o, Mw[OLD].e, Mw[OLD].o, Nw[OLD].o, Mw[P].e, Mw[P].o, Nw[P].o, so, wo);

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblanecv.so")
+_SO = os.environ.get("LANECV_SO") or os.path.join(_HERE, "liblanecv.so")   # LANECV_SO: another build of the same ABI (A/B runs)
 
 
 class error(Exception):
