@@ -120,7 +120,9 @@ template <int P> using Phase = std::integral_constant<int, P>;
 // GATE: the colour gate of the HSV-gated script in front of the gray conversion -- a pixel outside both
 // HSV boxes counts as black, so its gray value is 0.  The two 256-entry reciprocal tables sit in LDS (2 KiB
 // a workgroup; LDS reads have their own wait counter, so they do not disturb the grouped memory traffic).
-template <bool BLUR, bool GATE>
+// INTER: also store the gray (and blurred) images -- parity runs only; the variant without them keeps their
+// per-lane addresses out of the register budget.
+template <bool BLUR, bool GATE, bool INTER>
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     __shared__ int gtab[GATE ? 512 : 1];
     if constexpr (GATE) {
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
                                 (gate_keep(p2, gtab, a.gate) ? 0x00FF0000u : 0u) | (gate_keep(p3, gtab, a.gate) ? 0xFF000000u : 0u);
             G &= km;
         }
-        if (a.gray_out && v >= y0 && v < y1) {
+        if (INTER && a.gray_out && v >= y0 && v < y1) {
             if (inimg && emits) *reinterpret_cast<uint32_t *>(a.gray_out + (size_t)f * W * H + (size_t)v * W + px) = G;
         }
         return G;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             be = R32(U2(pkmad2(Tt[PREV].e, pkadd(Tt[OLD].e, Tt[P].e))) >> (unsigned short)8);
             bo = R32(U2(pkmad2(Tt[PREV].o, pkadd(Tt[OLD].o, Tt[P].o))) >> (unsigned short)8);
             const int bv = v - 2;
-            if (a.blur_out && bv >= y0 && bv < y1) {
+            if (INTER && a.blur_out && bv >= y0 && bv < y1) {
                 if (inimg && emits) *reinterpret_cast<uint32_t *>(a.blur_out + (size_t)f * W * H + (size_t)bv * W + px) = be | (bo << 8);
             }
         } else {
@@ -366,13 +368,13 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.nseg = (g.H + rows_per_unit - 1) / rows_per_unit;
     a.nunits = nframes * a.nseg * a.nstrips;
     dim3 grid((a.nunits + 3) / 4), block(256);
-    if (gate) {
-        if (blur) hipLaunchKernelGGL((k_front_stream<true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_front_stream<false, true>), grid, block, 0, st, a);
-    } else {
-        if (blur) hipLaunchKernelGGL((k_front_stream<true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_front_stream<false, false>), grid, block, 0, st, a);
-    }
+    const bool inter = gray_out || blur_out;
+#define LC_FS(B, G, I) hipLaunchKernelGGL((k_front_stream<B, G, I>), grid, block, 0, st, a)
+#define LC_FS2(B, G) do { if (inter) LC_FS(B, G, true); else LC_FS(B, G, false); } while (0)
+    if (gate) { if (blur) LC_FS2(true, true); else LC_FS2(false, true); }
+    else { if (blur) LC_FS2(true, false); else LC_FS2(false, false); }
+#undef LC_FS2
+#undef LC_FS
 }
 
 }  // namespace lanecv
