@@ -99,6 +99,80 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t *__restrict
     }
 }
 
+// The same for 3-channel frames whose output width is a multiple of 4: a thread makes four output pixels
+// (12 bytes, three dword stores) and reads its source bytes as whole dwords (three per pixel and row cover
+// the six bytes of the two taps; 24 contiguous bytes per row for the 2x2 mean).  src_bytes bounds the reads:
+// the few threads whose last dword would cross it take single bytes.
+__device__ __forceinline__ void taps6(const uint8_t *row, size_t base, size_t src_end, uint32_t &lo, uint32_t &hi) {
+    // lo = bytes base .. base+3, hi = bytes base+4, base+5 (upper half undefined)
+    const size_t al = base & ~(size_t)3;
+    if (al + 12 <= src_end) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(row + al);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], off = (uint32_t)(base - al);
+        lo = __builtin_amdgcn_alignbyte(d1, d0, off);
+        hi = __builtin_amdgcn_alignbyte(d2, d1, off);
+    } else {
+        auto at = [&](size_t i) -> uint32_t { return i < src_end ? row[i] : 0u; };   // only ever a zero-weight tap
+        lo = at(base) | (at(base + 1) << 8) | (at(base + 2) << 16) | (at(base + 3) << 24);
+        hi = at(base + 4) | (at(base + 5) << 8);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resize_linear3x4(const uint8_t *__restrict__ src, int sw, int sh, size_t src_bytes,
+                                                          uint8_t *__restrict__ dst, int dw, int dh,
+                                                          const int *__restrict__ xofs, const int *__restrict__ ia,
+                                                          const int *__restrict__ yofs, const int *__restrict__ ib, int area2) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, f = blockIdx.z;
+    const int dx0 = 4 * t;
+    if (dx0 >= dw) return;
+    const size_t frame = (size_t)sw * sh * 3, fbase = (size_t)f * frame;
+    uint32_t o[12];
+    if (area2) {
+        const size_t b0 = fbase + ((size_t)(2 * dy) * sw + 2 * dx0) * 3, b1 = b0 + (size_t)sw * 3;   // 24 bytes each, 8-byte aligned rows apart
+        uint32_t r0[6], r1[6];
+        if ((b0 & 3) == 0 && (b1 & 3) == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { r0[k] = reinterpret_cast<const uint32_t *>(src + b0)[k]; r1[k] = reinterpret_cast<const uint32_t *>(src + b1)[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                r0[k] = src[b0 + 4 * k] | (src[b0 + 4 * k + 1] << 8) | (src[b0 + 4 * k + 2] << 16) | ((uint32_t)src[b0 + 4 * k + 3] << 24);
+                r1[k] = src[b1 + 4 * k] | (src[b1 + 4 * k + 1] << 8) | (src[b1 + 4 * k + 2] << 16) | ((uint32_t)src[b1 + 4 * k + 3] << 24);
+            }
+        }
+        auto byte = [](const uint32_t (&r)[6], int i) -> uint32_t { return (r[i >> 2] >> (8 * (i & 3))) & 255u; };
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                o[3 * p + c] = (byte(r0, 6 * p + c) + byte(r0, 6 * p + 3 + c) + byte(r1, 6 * p + c) + byte(r1, 6 * p + 3 + c) + 2) >> 2;
+    } else {
+        const int sy = yofs[dy], b = ib[dy], wb0 = (short)(b & 0xFFFF), wb1 = b >> 16;
+        const size_t row0 = fbase + (size_t)min(max(sy, 0), sh - 1) * sw * 3, row1 = fbase + (size_t)min(max(sy + 1, 0), sh - 1) * sw * 3;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int sx = xofs[dx0 + p], a = ia[dx0 + p], a0 = (short)(a & 0xFFFF), a1 = a >> 16;
+            // the right tap's weight is 0 wherever it would fall outside the row (sx = sw - 1), so reading the
+            // six bytes at sx is enough: what lies behind the row's end is multiplied by zero
+            uint32_t l0, h0, l1, h1;
+            taps6(src, row0 + (size_t)sx * 3, src_bytes, l0, h0);
+            taps6(src, row1 + (size_t)sx * 3, src_bytes, l1, h1);
+            const uint32_t t0[6] = {l0 & 255, (l0 >> 8) & 255, (l0 >> 16) & 255, l0 >> 24, h0 & 255, (h0 >> 8) & 255};
+            const uint32_t t1[6] = {l1 & 255, (l1 >> 8) & 255, (l1 >> 16) & 255, l1 >> 24, h1 & 255, (h1 >> 8) & 255};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int hh0 = (int)t0[c] * a0 + (int)t0[3 + c] * a1;
+                const int hh1 = (int)t1[c] * a0 + (int)t1[3 + c] * a1;
+                o[3 * p + c] = (uint32_t)((((wb0 * (hh0 >> 4)) >> 16) + ((wb1 * (hh1 >> 4)) >> 16) + 2) >> 2) & 255u;
+            }
+        }
+    }
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst + ((size_t)f * dh + dy) * (size_t)dw * 3 + (size_t)dx0 * 3);
+    out[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+    out[1] = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+    out[2] = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -155,6 +229,11 @@ bool resize_tables_host(int sw, int sh, int dw, int dh, int *xofs, int *ia, int 
 void launch_resize_linear(const uint8_t *src, int sw, int sh, int cn, int nframes, uint8_t *dst, int dw, int dh,
                           const int *tabs, bool area2, hipStream_t st) {
     // tabs: xofs[dw], ia[dw], yofs[dh], ib[dh] back to back
+    if (cn == 3 && dw % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+        hipLaunchKernelGGL(k_resize_linear3x4, dim3((dw / 4 + 255) / 256, dh, nframes), dim3(256), 0, st, src, sw, sh,
+                           (size_t)sw * sh * 3 * nframes, dst, dw, dh, tabs, tabs + dw, tabs + 2 * dw, tabs + 2 * dw + dh, area2 ? 1 : 0);
+        return;
+    }
     hipLaunchKernelGGL(k_resize_linear, dim3((dw + 255) / 256, dh, nframes), dim3(256), 0, st, src, sw, sh, cn, dst, dw, dh, tabs,
                        tabs + dw, tabs + 2 * dw, tabs + 2 * dw + dh, area2 ? 1 : 0);
 }
