@@ -29,10 +29,36 @@ __device__ __forceinline__ bool gate_pass(int h, int s, int v, const GateDev &gt
 }
 
 // p = B | G << 8 | R << 16 (bits 24-31 ignored): does the gate keep the pixel?
+// SHAPE 1 is the general form.  SHAPE 2 is the form of the lane script's two boxes, whatever their numbers
+// (gate_shape decides): box 0 = "any hue, saturation at most s0, value at least v0", box 1 = "hue inside
+// [a, b] with b < 150, saturation at least s1, value at least v1".  One-sided tests are a single compare, and
+// a hue interval below 150 needs no wrap of negative hues (they become 150..179, outside it; tested unwrapped
+// they are negative, which the unsigned compare rejects as well).
+template <int SHAPE>
 __device__ __forceinline__ bool gate_keep(uint32_t p, const int *tab, const GateDev &gt) {
-    int h, s, v;
-    hsv_px((int)(p & 255u), (int)((p >> 8) & 255u), (int)((p >> 16) & 255u), tab, h, s, v);
-    return gate_pass(h, s, v, gt);
+    const int b = (int)(p & 255u), g = (int)((p >> 8) & 255u), r = (int)((p >> 16) & 255u);
+    if constexpr (SHAPE == 2) {
+        const int v = max(b, max(g, r)), diff = v - min(b, min(g, r));
+        const int sd = tab[v], hd = tab[256 + diff];
+        const int s = (diff * sd + (1 << 11)) >> 12;
+        const int hh = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+        const int h = (hh * hd + (1 << 11)) >> 12;                       // not wrapped
+        const bool in0 = s <= (int)gt.span[1] && v >= gt.lo[2];          // box 0: lo[1] is 0, so span[1] is the upper bound
+        const bool in1 = (uint32_t)(h - gt.lo[3]) <= gt.span[3] && s >= gt.lo[4] && v >= gt.lo[5];
+        return in0 || in1;
+    } else {
+        int h, s, v;
+        hsv_px(b, g, r, tab, h, s, v);
+        return gate_pass(h, s, v, gt);
+    }
+}
+
+// 2 when the (normalised) gate has the lane script's form described above, else 1
+inline int gate_shape(const GateDev &gt) {
+    auto upper_open = [&](int i) { return gt.lo[i] <= 255 && gt.lo[i] + (long long)gt.span[i] >= 255; };   // no upper bound
+    const bool box0 = gt.lo[0] == 0 && gt.span[0] >= 179 && gt.lo[1] == 0 && gt.lo[2] <= 255 && upper_open(2);
+    const bool box1 = gt.lo[3] <= 255 && gt.lo[3] + (long long)gt.span[3] < 150 && upper_open(4) && upper_open(5);
+    return box0 && box1 ? 2 : 1;
 }
 
 }  // namespace lanecv

@@ -117,15 +117,15 @@ constexpr int STRIP = 248;        // output columns of a wavefront
 
 template <int P> using Phase = std::integral_constant<int, P>;
 
-// GATE: the colour gate of the HSV-gated script in front of the gray conversion -- a pixel outside both
+// GATE != 0: the colour gate of the HSV-gated script in front of the gray conversion -- a pixel outside both
 // HSV boxes counts as black, so its gray value is 0.  The two 256-entry reciprocal tables sit in LDS (2 KiB
 // a workgroup; LDS reads have their own wait counter, so they do not disturb the grouped memory traffic).
 // INTER: also store the gray (and blurred) images -- parity runs only; the variant without them keeps their
 // per-lane addresses out of the register budget.
-template <bool BLUR, bool GATE, bool INTER>
+template <bool BLUR, int GATE, bool INTER>   // GATE: 0 none, 1 general, 2 the lane script's form (gate_keep)
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     __shared__ int gtab[GATE ? 512 : 1];
-    if constexpr (GATE) {
+    if constexpr (GATE != 0) {
         for (int i = threadIdx.x; i < 512; i += 256) gtab[i] = a.gate_tab[i];
         __syncthreads();
     }
@@ -195,9 +195,9 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         const uint32_t t2 = (dot4(p2, a.k_hi, 0) << 8) + dot4(p2, a.k_lo, 1u << 15);
         const uint32_t t3 = (dot4(p3, a.k_hi, 0) << 8) + dot4(p3, a.k_lo, 1u << 15);
         uint32_t G = __builtin_amdgcn_perm(t1, t0, 0x0c0c0602u) | __builtin_amdgcn_perm(t3, t2, 0x06020c0cu);
-        if constexpr (GATE) {
-            const uint32_t km = (gate_keep(p0, gtab, a.gate) ? 0x000000FFu : 0u) | (gate_keep(p1, gtab, a.gate) ? 0x0000FF00u : 0u) |
-                                (gate_keep(p2, gtab, a.gate) ? 0x00FF0000u : 0u) | (gate_keep(p3, gtab, a.gate) ? 0xFF000000u : 0u);
+        if constexpr (GATE != 0) {
+            const uint32_t km = (gate_keep<GATE>(p0, gtab, a.gate) ? 0x000000FFu : 0u) | (gate_keep<GATE>(p1, gtab, a.gate) ? 0x0000FF00u : 0u) |
+                                (gate_keep<GATE>(p2, gtab, a.gate) ? 0x00FF0000u : 0u) | (gate_keep<GATE>(p3, gtab, a.gate) ? 0xFF000000u : 0u);
             G &= km;
         }
         if (INTER && a.gray_out && v >= y0 && v < y1) {
@@ -371,8 +371,10 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     const bool inter = gray_out || blur_out;
 #define LC_FS(B, G, I) hipLaunchKernelGGL((k_front_stream<B, G, I>), grid, block, 0, st, a)
 #define LC_FS2(B, G) do { if (inter) LC_FS(B, G, true); else LC_FS(B, G, false); } while (0)
-    if (gate) { if (blur) LC_FS2(true, true); else LC_FS2(false, true); }
-    else { if (blur) LC_FS2(true, false); else LC_FS2(false, false); }
+    const int shape = gate ? gate_shape(*gate) : 0;
+    if (shape == 2) { if (blur) LC_FS2(true, 2); else LC_FS2(false, 2); }
+    else if (shape == 1) { if (blur) LC_FS2(true, 1); else LC_FS2(false, 1); }
+    else { if (blur) LC_FS2(true, 0); else LC_FS2(false, 0); }
 #undef LC_FS2
 #undef LC_FS
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_gate_gray(const uint8_t *__restrict__ s
     if (p0 >= npix) return;
     auto one = [&](uint32_t px) -> uint32_t {   // px = c0 | c1 << 8 | c2 << 16
         const uint32_t gy = ((px & 255) * k0 + ((px >> 8) & 255) * k1 + ((px >> 16) & 255) * k2 + (1 << 14)) >> 15;
-        return gate_keep(px, tab, gate) ? gy : 0u;
+        return gate_keep<1>(px, tab, gate) ? gy : 0u;
     };
     if (p0 + 4 <= npix) {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(src) + q * 3;

@@ -127,3 +127,42 @@ def test_gate_changes_the_result(oracle):
         pipe.close()
     assert (out["none"] == out["all"]).all()
     assert (out["none"] != out["script"]).any()
+
+
+GATES = [
+    WHITE_YELLOW,                                                         # the script's numbers (one-sided form)
+    ((0, 0, 180), (180, 60, 255), (10, 80, 80), (40, 255, 255)),         # same form, other sensitivities
+    ((0, 0, 0), (179, 255, 255), (0, 0, 0), (149, 255, 255)),            # same form at its limits: keeps everything
+    ((0, 0, 200), (180, 30, 255), (15, 100, 100), (150, 255, 255)),      # hue interval reaches the wrapped hues
+    ((160, 50, 50), (179, 200, 220), (0, 10, 10), (5, 250, 250)),        # two-sided boxes, red hues on both ends
+    ((0, 0, 200), (180, 30, 254), (15, 100, 100), (35, 255, 255)),       # an upper bound on V
+    ((50, 0, 0), (40, 255, 255), (15, 100, 100), (35, 90, 255)),         # both boxes empty
+]
+
+
+@pytest.mark.parametrize("gi", range(len(GATES)))
+def test_fused_gate_forms(oracle, gi):
+    """The streaming kernel has a general gate and a cheaper form for boxes shaped like the script's; both must
+    give the oracle's gated gray, with and without the intermediate images."""
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h = 640, 360
+    gate = GATES[gi]
+    rng = np.random.default_rng(gi)
+    sat = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    sat[:, : w // 2, 0] = sat[:, : w // 2, 1]                              # left half: many b == g ties and low saturation
+    frames = np.stack([synth.synth_road(w, h, seed=9, t=3), synth.adversarial_frames(w, h)["noise"], sat])
+    masked = {}
+    for keep in (True, False):
+        rec = Recipe.hsv_gated(w, h)
+        rec.hsv_gate, rec.segments = gate, False
+        pipe = LanePipeline(w, h, rec, max_batch=3, nslots=1, keep_intermediates=keep)
+        pipe.submit(0, frames)
+        pipe.wait(0)
+        masked[keep] = pipe.read(0, _abi.BUF_MASKED)
+        if keep:
+            gray = pipe.read(0, _abi.BUF_GRAY)
+            for i, f in enumerate(frames):
+                assert (gray[i] == oracle.gate_gray(f, gate)).all(), i
+        pipe.close()
+    assert (masked[True] == masked[False]).all()
