@@ -728,6 +728,10 @@ struct lc_pipe {
     //             CU's LDS: on a high-priority stream the dispatcher places it ahead of the next batch's
     //             front-end waves instead of behind them.
     hipStream_t st_up = nullptr, st_edge = nullptr, st_lines = nullptr;
+    // Second HoughLinesP stream (experimental, LANECV_LINES_STREAMS=2): batches alternate between the two, so
+    // that the workgroups of the next batch start on the CUs whose frame of this batch finished early.
+    hipStream_t st_lines2 = nullptr;
+    unsigned lines_turn = 0;
     // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs), while the short
     // latency-bound kernels behind the front end leave the GPU half empty.  So the HoughLinesP step of a batch
     // is not queued when the batch is submitted but when the NEXT one is, behind that batch's front-end kernel:
@@ -779,7 +783,7 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
     const bool vote_fused = p.want_accumulator && p.want_segments;
     hipStream_t ls = es;   // the stream the batch finishes on
     if (p.want_segments) {
-        ls = pp->st_lines;
+        ls = (pp->st_lines2 && (pp->lines_turn++ & 1)) ? pp->st_lines2 : pp->st_lines;
         if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[EV_POINTS], 0);
         if (ls != es && after) (void)hipStreamWaitEvent(ls, after, 0);
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
@@ -937,6 +941,12 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         }
         if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
         if (!pp->st_lines) pp->st_lines = pp->st_edge;
+        const char *ns = getenv("LANECV_LINES_STREAMS");
+        if (ns && ns[0] == '2' && pp->st_lines != pp->st_edge) {
+            int lo_pri = 0, hi_pri = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+            if (hipStreamCreateWithPriority(&pp->st_lines2, hipStreamNonBlocking, hi_pri) != hipSuccess) pp->st_lines2 = nullptr;
+        }
     }
     pp->slots.resize(p.nslots);
     for (Slot &s : pp->slots) {
@@ -983,6 +993,7 @@ int lc_pipe_destroy(lc_pipe *pipe) {
     if (pipe->st_up) (void)hipStreamSynchronize(pipe->st_up);
     if (pipe->st_edge) (void)hipStreamSynchronize(pipe->st_edge);
     if (pipe->st_lines) (void)hipStreamSynchronize(pipe->st_lines);
+    if (pipe->st_lines2) { (void)hipStreamSynchronize(pipe->st_lines2); (void)hipStreamDestroy(pipe->st_lines2); }
     for (Slot &s : pipe->slots) {
         for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
         if (s.h_res) (void)hipHostFree(s.h_res);

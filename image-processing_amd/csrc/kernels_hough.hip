@@ -177,6 +177,7 @@ struct Walk {
 __device__ long long g_stamps[8];   // diagnostic build only: cycle sums of frame 0
 __device__ unsigned long long g_dbg[4];
 __device__ int g_simd[8];
+__device__ long long g_frame_cycles[1024];   // consumer loop and whole kernel (set-up included) per frame: [2f], [2f + 1]
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
 #ifndef PPHT_Q
@@ -224,7 +225,10 @@ __device__ __forceinline__ bool lds_mask_bit(const Ppht &c, int j, int i, uint32
 // the shape of the voting step.  One job is in flight at a time and every worker reports before the
 // next is posted, so helpers see every job exactly once.
 constexpr int LINE_NC = 4;                       // 64-step chunks per direction fetched (and posted) together
-constexpr int PPHT_THREADS = 512, JOB_WORKERS = 7;   // waves: 0 consumer, 1 producer, 2..7 helpers
+#ifndef PPHT_WAVES
+#define PPHT_WAVES 8
+#endif
+constexpr int PPHT_THREADS = 64 * PPHT_WAVES, JOB_WORKERS = PPHT_WAVES - 1;   // waves: 0 consumer, 1 producer, 2.. helpers
 struct Jobs {
     int seq;                     // jobs posted so far; -1 tells the helpers to leave
     int done;                    // workers that finished job `seq`
@@ -659,6 +663,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef LC_STAMPS
     if (f == 0 && lane == 0) g_simd[wave] = __builtin_amdgcn_s_getreg(2308);
+    const long long t_kernel0 = STAMP();
 #endif
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
     const int n = npoints[f];
@@ -1021,6 +1026,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
         g_stamps[1] = STAMP() - tc0; g_stamps[2] = t_wait; g_stamps[3] = t_vote; g_stamps[4] = t_line;
         g_stamps[5] = n_alive; g_stamps[6] = n_line; g_stamps[7] = n;
     }
+    if (f < 512 && lane == 0) { g_frame_cycles[2 * f] = STAMP() - tc0; g_frame_cycles[2 * f + 1] = STAMP() - t_kernel0; }
 #endif
 }
 
@@ -1090,6 +1096,9 @@ extern "C" int lc_debug_stamps(long long *out) {
     (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_dbg), sizeof(long long) * 4);
     (void)hipMemcpyFromSymbol(out + 12, HIP_SYMBOL(g_simd), sizeof(int) * 8);
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 8);
+}
+extern "C" int lc_debug_frame_cycles(long long *out, int nframes) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_frame_cycles), sizeof(long long) * 2 * (nframes < 512 ? nframes : 512));
 }
 #endif
 

@@ -17,3 +17,9 @@ print('rc', _abi.lib().lc_debug_stamps(out))
 names=['producer_cycles','consumer_cycles','wait','vote','line','n_alive','n_line','n']
 print({k:int(v) for k,v in zip(names,out)}); print('dbg', list(out)[8:12]); import struct; print('simd', struct.unpack('8i', struct.pack('4q', *list(out)[12:16])))
 print('lines ms', pipe.stage_ms(0,_abi.STAGE_LINES))
+fc = (C.c_longlong * (2 * B))()
+_abi.lib().lc_debug_frame_cycles(fc, B)
+a = np.array(list(fc), dtype=np.int64).reshape(B, 2)
+for name, col in (("consumer loop", a[:, 0]), ("whole kernel", a[:, 1])):
+    print(name, "cycles per frame: min %d  median %d  mean %d  max %d" % (col.min(), np.median(col), col.mean(), col.max()))
+print("slowest frames", np.argsort(a[:, 1])[-5:], "set-up (kernel - loop) median", int(np.median(a[:, 1] - a[:, 0])))
