@@ -47,11 +47,11 @@ def make_frames(seed, n, workers):
 def pmc_traffic(batch):
     """HBM bytes per k_front_stream launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
     WRITE_SIZE runs, FETCH_SIZE doubled as gfx950 needs); None when the launch shape differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "round1_v5_pmc_edge_stage.json")
+    path = os.path.join(ROOT, "profiles", "round1_v6_pmc_edge_stage.json")
     if batch != 256 or not os.path.exists(path):
         return None
     with open(path) as fh:
-        return round(json.load(fh)["kernels"]["k_front_stream<true, false>"]["traffic_bytes"])
+        return round(json.load(fh)["kernels"]["k_front_stream<true, 0, false>"]["traffic_bytes"])
 
 
 def cpu_baseline(frames, rec, roi, threads):
@@ -174,7 +174,7 @@ def main():
                                    "-> HoughLinesP(6, pi/60, 160, 40, 25); inputs resident in HBM" % batch,
                        "width": W, "height": H, "batch": batch, "slots_in_flight": args.slots,
                        "sharding": "one clip per GPU, no data-path collective, final segment gather"},
-            "roofline": {"bound": "hbm", "kernel": "k_front_stream<true, false>",
+            "roofline": {"bound": "hbm", "kernel": "k_front_stream<true, 0, false>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(batch),
                          "algorithmic_bytes_per_launch": front_bytes, "launch_ms": round(front_ms, 4),
@@ -196,7 +196,7 @@ def main():
             pipe.wait(0)
             excl.append({n: pipe.stage_ms(0, i) for n, i in stage_names.items()})
         em = {n: float(np.median([s[n] for s in excl])) for n in stage_names}
-        out["roofline_exclusive"] = {"kernel": "k_front_stream<true, false>, nothing else on the GPU", "launch_ms": round(em["front"], 4),
+        out["roofline_exclusive"] = {"kernel": "k_front_stream<true, 0, false>, nothing else on the GPU", "launch_ms": round(em["front"], 4),
                                      "achieved": round(front_bytes / (em["front"] * 1e-3) / 1e9, 1),
                                      "frac": round(front_bytes / (em["front"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "stage_ms": {k: round(v, 4) for k, v in em.items()}}
