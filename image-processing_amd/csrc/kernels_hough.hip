@@ -224,7 +224,11 @@ __device__ __forceinline__ bool lds_mask_bit(const Ppht &c, int j, int i, uint32
 // pixel from the walk with scalar arithmetic and subtracts its vote with one angle per lane, exactly
 // the shape of the voting step.  One job is in flight at a time and every worker reports before the
 // next is posted, so helpers see every job exactly once.
-constexpr int LINE_NC = 4;                       // 64-step chunks per direction fetched (and posted) together
+// 64-step chunks per direction fetched (and posted) together.  One at a time with the state in LDS: the staged
+// fetch of four kept 72 VGPRs alive (103 for the kernel, 77 with one -- which lets a fourth front-end wave per SIMD
+// run beside this kernel), and a job per 64 steps lets the helpers take votes back while the walker clears the
+// next chunk.  From global memory a round trip is expensive, so the general kernel takes four.
+constexpr int LINE_NC = 1, LINE_NC_GLOBAL = 4;
 #ifndef PPHT_WAVES
 #define PPHT_WAVES 8
 #endif
@@ -393,7 +397,7 @@ struct LineOut {
 template <bool LDS_STATE>
 __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int i, int max_n, int nseg, Jobs *jb, int jobseq,
                                             const VoteLane &vl, LineOut &lo) {
-    constexpr int NC = LINE_NC;
+    constexpr int NC = LDS_STATE ? LINE_NC : LINE_NC_GLOBAL;
     bool inflight = false;   // a vote-removal job of this line is with the helpers
     const AngleEntry e = LDS_STATE ? c.ltab[max_n] : c.tab[max_n];
     Walk wk;
