@@ -732,6 +732,7 @@ struct lc_pipe {
     // that the workgroups of the next batch start on the CUs whose frame of this batch finished early.
     hipStream_t st_lines2 = nullptr;
     unsigned lines_turn = 0;
+
     // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs), while the short
     // latency-bound kernels behind the front end leave the GPU half empty.  So the HoughLinesP step of a batch
     // is not queued when the batch is submitted but when the NEXT one is, behind that batch's front-end kernel:

@@ -374,12 +374,11 @@ __device__ __forceinline__ uint32_t ldF(const uint32_t *p) {
 __device__ __forceinline__ void stF(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__restrict__ planeS,
-                                                           const uint64_t *__restrict__ planeW,
-                                                           uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
-                                                           int *__restrict__ rounds_out) {
-    __shared__ int any;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// the rounds of one frame, run by the HC_THREADS threads of a workgroup; `any` is a word of LDS
+__device__ __forceinline__ void hysteresis_frame(const Geo &g, int f, uint64_t *__restrict__ planeS,
+                                                 const uint64_t *__restrict__ planeW, uint32_t *__restrict__ wakeA,
+                                                 uint32_t *__restrict__ wakeB, int *__restrict__ rounds_out, int &any) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = g.TX * g.TY;
     uint32_t *cur = wakeA + (size_t)f * ntile, *nxt = wakeB + (size_t)f * ntile;   // nxt starts all zero
     int mine = 0;
@@ -412,6 +411,14 @@ __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__re
         rounds++;
     }
     if (tid == 0 && rounds_out) rounds_out[f] = rounds;
+}
+
+__global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__restrict__ planeS,
+                                                           const uint64_t *__restrict__ planeW,
+                                                           uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
+                                                           int *__restrict__ rounds_out) {
+    __shared__ int any;
+    hysteresis_frame(g, blockIdx.x, planeS, planeW, wakeA, wakeB, rounds_out, any);
 }
 
 // ---------------------------------------------------------------------------
@@ -479,23 +486,15 @@ __global__ __launch_bounds__(256) void k_finalize(Geo g, int ntiles_total, const
 // or have an edge pixel are written -- a few per cent of the map.  The same holds for the plane word handed to
 // the Hough stage (which only ever clears bits of it) and for the row counts (their consumer clears them).
 // One thread per 64-pixel word, words in memory order.
-__global__ __launch_bounds__(256) void k_finalize_sparse(Geo g, size_t nwords, const uint64_t *__restrict__ planeS,
-                                                         const uint64_t *__restrict__ roi_bits, uint64_t *__restrict__ prevbits,
-                                                         uint8_t *__restrict__ masked_out, uint64_t *__restrict__ rowplane,
-                                                         int *__restrict__ rowcount) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nwords) return;
-    const size_t words_per_frame = (size_t)g.TX * g.H;
-    const size_t f = i / words_per_frame, wf = i % words_per_frame;   // wf = y * TX + tx
-    uint64_t M = planeS[i];
-    if (roi_bits) M &= roi_bits[wf];
-    const uint64_t P = prevbits[i];
+// one plane word: M = its masked bits now, P = the bits written last time
+__device__ __forceinline__ void finalize_word(const Geo &g, size_t f, size_t wf, size_t i, uint64_t M, uint64_t P,
+                                              uint64_t *__restrict__ prevbits, uint8_t *__restrict__ masked_out,
+                                              uint64_t *__restrict__ rowplane) {
     const uint64_t D = M | P;
     if (D == 0) return;
     if (rowplane) rowplane[i] = M;
     if (M != P) prevbits[i] = M;
     const int y = (int)(wf / g.TX), tx = (int)(wf % g.TX);
-    if (M && rowcount) atomicAdd(&rowcount[f * g.H + y], __popcll(M));
     const int W = g.W;
     const bool vec_ok = (W % 16) == 0;
     const size_t o = f * (size_t)W * g.H + (size_t)y * W + (size_t)tx * TILE;
@@ -513,6 +512,21 @@ __global__ __launch_bounds__(256) void k_finalize_sparse(Geo g, size_t nwords, c
             for (int j = 0; j < n; j++) masked_out[o + 16 * q + j] = (mb >> j) & 1 ? 255 : 0;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_finalize_sparse(Geo g, size_t nwords, const uint64_t *__restrict__ planeS,
+                                                         const uint64_t *__restrict__ roi_bits, uint64_t *__restrict__ prevbits,
+                                                         uint8_t *__restrict__ masked_out, uint64_t *__restrict__ rowplane,
+                                                         int *__restrict__ rowcount) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nwords) return;
+    const size_t words_per_frame = (size_t)g.TX * g.H;
+    const size_t f = i / words_per_frame, wf = i % words_per_frame;   // wf = y * TX + tx
+    uint64_t M = planeS[i];
+    if (roi_bits) M &= roi_bits[wf];
+    const uint64_t P = prevbits[i];
+    if (M && rowcount) atomicAdd(&rowcount[f * g.H + wf / g.TX], __popcll(M));
+    finalize_word(g, f, wf, i, M, P, prevbits, masked_out, rowplane);
 }
 
 // bitwise_and with an optional mask (dst = 0 where mask == 0)
