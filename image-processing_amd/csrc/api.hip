@@ -732,6 +732,9 @@ struct lc_pipe {
     // that the workgroups of the next batch start on the CUs whose frame of this batch finished early.
     hipStream_t st_lines2 = nullptr;
     unsigned lines_turn = 0;
+    // Stream of the short latency-bound kernels behind the front kernel (hysteresis, finalize, compaction); when
+    // it is st_edge itself they queue behind their front kernel and in front of the next one.
+    hipStream_t st_post = nullptr;
 
     // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs), while the short
     // latency-bound kernels behind the front end leave the GPU half empty.  So the HoughLinesP step of a batch
@@ -754,7 +757,7 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     Work &w = s.w;
     const lc_pipe_params &p = pp->p;
     const int n = s.nframes;
-    hipStream_t es = pp->st_edge;
+    hipStream_t es = pp->st_post;
     const bool hough = p.want_accumulator || p.want_segments;
     const bool points = hough || p.want_points;
     if (!points) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
@@ -780,7 +783,7 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
     Work &w = s.w;
     const lc_pipe_params &p = pp->p;
     const int n = s.nframes;
-    hipStream_t es = pp->st_edge;
+    hipStream_t es = pp->st_post;
     const bool vote_fused = p.want_accumulator && p.want_segments;
     hipStream_t ls = es;   // the stream the batch finishes on
     if (p.want_segments) {
@@ -835,8 +838,10 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
                  pp->has_gate ? &pp->gate : nullptr, pp->ctx->hsv_tab.p, w.gray.p);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
-    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, es);
-    HIP_TRY(hipEventRecord(s.ev[EV_HYST], es));
+    hipStream_t ps = pp->st_post;
+    if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, s.ev[EV_FRONT], 0));
+    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps);
+    HIP_TRY(hipEventRecord(s.ev[EV_HYST], ps));
     if (pp->deferred >= 0) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_HYST]); pp->deferred = -1; }
     enqueue_back(pp, s);
     HIP_TRY(hipGetLastError());
@@ -942,11 +947,14 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         }
         if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
         if (!pp->st_lines) pp->st_lines = pp->st_edge;
-        const char *ns = getenv("LANECV_LINES_STREAMS");
-        if (ns && ns[0] == '2' && pp->st_lines != pp->st_edge) {
+        // the short kernels get a high-priority stream of their own when batches are pipelined: the next batch's
+        // front kernel then starts at once and they run beside it (LANECV_POST_STREAM=0: keep them on st_edge)
+        pp->st_post = pp->st_edge;
+        const char *po = getenv("LANECV_POST_STREAM");
+        if (p.nslots > 1 && !(po && po[0] == '0')) {
             int lo_pri = 0, hi_pri = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
-            if (hipStreamCreateWithPriority(&pp->st_lines2, hipStreamNonBlocking, hi_pri) != hipSuccess) pp->st_lines2 = nullptr;
+            if (hipStreamCreateWithPriority(&pp->st_post, hipStreamNonBlocking, hi_pri) != hipSuccess) pp->st_post = pp->st_edge;
         }
     }
     pp->slots.resize(p.nslots);
@@ -995,6 +1003,7 @@ int lc_pipe_destroy(lc_pipe *pipe) {
     if (pipe->st_edge) (void)hipStreamSynchronize(pipe->st_edge);
     if (pipe->st_lines) (void)hipStreamSynchronize(pipe->st_lines);
     if (pipe->st_lines2) { (void)hipStreamSynchronize(pipe->st_lines2); (void)hipStreamDestroy(pipe->st_lines2); }
+    if (pipe->st_post && pipe->st_post != pipe->st_edge) { (void)hipStreamSynchronize(pipe->st_post); (void)hipStreamDestroy(pipe->st_post); }
     for (Slot &s : pipe->slots) {
         for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
         if (s.h_res) (void)hipHostFree(s.h_res);
