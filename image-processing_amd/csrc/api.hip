@@ -714,33 +714,26 @@ struct lc_pipe {
     int src_w = 0, src_h = 0;
     size_t src_frame_bytes = 0;   // bytes of one submitted frame
     DevBuf<int> resize_tab;
-    // A pipeline owns three streams, whatever its number of slots; a slot is a set of buffers and events.
-    // (HIP maps streams onto a few hardware queues.  Streams that share one see each other's event waits as
-    // barriers, which at best serialises batches that should overlap and at worst ties two queues into a
-    // knot, so the count stays below the number of hardware queues.  The waits between them also run one way
-    // only -- st_up -> st_edge -> st_lines: pairs of streams that waited on each other in turn have hung.)
+    // A pipeline owns four streams, whatever its number of slots; a slot is a set of buffers and events.
+    // (HIP maps streams onto a few hardware queues, so the count stays small; and the waits between streams run one
+    // way only -- st_up -> st_edge -> st_post -> st_lines: pairs of streams that waited on each other in turn have
+    // hung, as has a layout with a HoughLinesP stream per slot.)
     //   st_up     host-to-device copies of submitted frames.
-    //   st_edge   everything before HoughLinesP (front end, hysteresis, compaction) of all slots, in
-    //             submission order.  Those kernels fill the GPU by themselves, so two batches gain nothing
-    //             from running them side by side; what pays is HoughLinesP of batch k beside the edge stage
-    //             of batch k + 1, and serialising the edge stages keeps the slots in that alternating rhythm.
-    //   st_lines  HoughLinesP and the copies of its results.  One workgroup per frame that wants most of a
-    //             CU's LDS: on a high-priority stream the dispatcher places it ahead of the next batch's
-    //             front-end waves instead of behind them.
-    hipStream_t st_up = nullptr, st_edge = nullptr, st_lines = nullptr;
-    // Second HoughLinesP stream (experimental, LANECV_LINES_STREAMS=2): batches alternate between the two, so
-    // that the workgroups of the next batch start on the CUs whose frame of this batch finished early.
+    //   st_edge   the front kernels (and the leading resize) of all slots, in submission order, back to back.
+    //             They fill the GPU by themselves, so two of them gain nothing from running side by side.
+    //   st_post   the short latency-bound kernels behind a front kernel: hysteresis, finalize, compaction (and the
+    //             vote kernel of accumulator-only recipes).  High priority, so that their few workgroups are placed
+    //             ahead of the next front kernel's thousands; with a single slot it is st_edge itself.
+    //   st_lines  HoughLinesP and the copy of the batch's results.  One workgroup per frame that wants most of a
+    //             CU's LDS: high priority for the same reason.
+    hipStream_t st_up = nullptr, st_edge = nullptr, st_post = nullptr, st_lines = nullptr;
+    // Second HoughLinesP stream (diagnostics, LANECV_LINES_STREAMS=2): batches alternate between the two.
     hipStream_t st_lines2 = nullptr;
     unsigned lines_turn = 0;
-    // Stream of the short latency-bound kernels behind the front kernel (hysteresis, finalize, compaction); when
-    // it is st_edge itself they queue behind their front kernel and in front of the next one.
-    hipStream_t st_post = nullptr;
 
-    // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs), while the short
-    // latency-bound kernels behind the front end leave the GPU half empty.  So the HoughLinesP step of a batch
-    // is not queued when the batch is submitted but when the NEXT one is, behind that batch's front-end kernel:
-    // it then runs beside the next batch's hysteresis / finalize / compaction and only the rest of it beside a
-    // front end.  `deferred` is the slot whose HoughLinesP step is still to be queued (-1: none); waiting for
+    // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs).  The HoughLinesP
+    // step of a batch is therefore not queued when the batch is submitted but when the NEXT one is, behind that
+    // batch's front-end kernel: started at submit time it would run beside two front kernels in a row.  `deferred` is the slot whose HoughLinesP step is still to be queued (-1: none); waiting for
     // that slot queues it at once.  defer_after: 0 = never defer, 1 = behind the front end, 2 = behind hysteresis.
     int deferred = -1;
     int defer_after = 1;
