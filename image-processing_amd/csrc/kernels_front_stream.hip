@@ -357,8 +357,9 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.k_hi = (k0 >> 8) | ((k1 >> 8) << 8) | ((k2 >> 8) << 16);
     a.nstrips = (TILE * g.TX + STRIP - 1) / STRIP;   // every byte of every plane row is written
     if (rows_per_unit <= 0) {
-        // enough units to load every CU a few times over, few enough to keep the 8 halo rows cheap
-        int want = 16384 / (nframes * a.nstrips > 0 ? nframes * a.nstrips : 1);
+        // enough units to load every CU many times over (80 per CU measured best beside HoughLinesP: finer units
+        // balance better around its resident workgroups), few enough to keep the 8 halo rows cheap
+        int want = 20480 / (nframes * a.nstrips > 0 ? nframes * a.nstrips : 1);
         if (want < 1) want = 1;
         rows_per_unit = (g.H + want - 1) / want;
         if (rows_per_unit < 64) rows_per_unit = 64;
