@@ -157,7 +157,7 @@ struct Work {
         HIP_TRY(hipMemset(rowcount.p, 0, sizeof(int) * (size_t)B * H));
         if ((rc = npoints.alloc(B))) return rc;
         if ((rc = segcount.alloc(B))) return rc;
-        if ((rc = status.alloc(1))) return rc;
+        if ((rc = status.alloc(2))) return rc;
         if ((rc = fallback.alloc(B))) return rc;
         return LC_OK;
     }
@@ -660,18 +660,18 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
     const int na = wk.hg.numangle, nr = wk.hg.numrho;
     if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
     if ((rc = points_from_bytes(ctx, nullptr))) return rc;
-    HIP_TRY(hipMemsetAsync(wk.status.p, 0, sizeof(int), ctx->stream));
+    HIP_TRY(hipMemsetAsync(wk.status.p, 0, 2 * sizeof(int), ctx->stream));
     const int line_length = (int)lrint(min_line_length), line_gap = (int)lrint(max_line_gap);
     const bool fast = launch_ppht_fast(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, threshold, line_length,
                                        line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, RNG_TABLE,
                                        nullptr, ctx->stream);
     launch_ppht_general(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, wk.acc_ppht.p, threshold, line_length,
                         line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, fast ? wk.fallback.p : nullptr, ctx->stream);
-    int host[2] = {0, 0};
+    int host[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(&host[0], wk.segcount.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&host[1], wk.status.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&host[1], wk.status.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (host[1]) return fail(LC_EINVAL, "HoughLinesP: internal range error (status %d)", host[1]);
+    if (host[1] | host[2]) return fail(LC_EINVAL, "HoughLinesP: internal range error (status %d)", host[1] | (host[2] << 1));
     *n = host[0];
     const int ncopy = std::min(host[0], capacity);
     if (ncopy > 0) {
@@ -696,6 +696,7 @@ struct Slot {
     bool busy = false, timed = false;
     // pinned host mirror of the slot's result block
     int32_t *h_res = nullptr;
+    bool zero_copy = false;       // the kernels write the result block straight into h_res (mapped pinned memory)
     int *h_rounds = nullptr, *h_status = nullptr, *h_segcount = nullptr;
     int32_t *h_seg = nullptr;
 };
@@ -801,9 +802,10 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
         (void)hipEventRecord(s.ev[EV_LINES], ls);
     }
-    // one copy: counts, rounds, status and (if wanted) the segments of the n frames
-    const size_t res_ints = w.res_head + (p.want_segments ? (size_t)n * w.seg_cap * 4 : 0);
-    (void)hipMemcpyAsync(s.h_res, w.resblock.p, sizeof(int32_t) * res_ints, hipMemcpyDeviceToHost, ls);
+    if (!s.zero_copy) {   // one copy: counts, rounds, status and (if wanted) the segments of the n frames
+        const size_t res_ints = w.res_head + (p.want_segments ? (size_t)n * w.seg_cap * 4 : 0);
+        (void)hipMemcpyAsync(s.h_res, w.resblock.p, sizeof(int32_t) * res_ints, hipMemcpyDeviceToHost, ls);
+    }
     (void)hipEventRecord(s.ev[EV_END], ls);
 }
 
@@ -983,6 +985,16 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         memset(s.h_res, 0, sizeof(int32_t) * s.w.res_head);
         s.h_segcount = s.h_res; s.h_rounds = s.h_res + p.max_batch; s.h_status = s.h_res + 2 * (size_t)p.max_batch;
         s.h_seg = s.h_res + s.w.res_head;
+        // What goes back per batch is a few hundred bytes per frame, written once: the kernels store it into the
+        // pinned block directly, which takes a copy and its launch off the HoughLinesP stream
+        // (LANECV_RESULT_COPY=1 keeps the device block and the copy).
+        const char *rc_env = getenv("LANECV_RESULT_COPY");
+        void *dp = nullptr;
+        if (!(rc_env && rc_env[0] == '1') && hipHostGetDevicePointer(&dp, s.h_res, 0) == hipSuccess && dp) {
+            int32_t *d = (int32_t *)dp;
+            s.w.r_segcount = d; s.w.r_rounds = d + p.max_batch; s.w.r_status = d + 2 * (size_t)p.max_batch; s.w.r_seg = d + s.w.res_head;
+            s.zero_copy = true;
+        }
     }
     *out = pp;
     return LC_OK;
@@ -1046,7 +1058,8 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
     if (p.want_segments) {
-        if (*s->h_status) return fail(LC_ECAP, "HoughLinesP: a frame holds more edge points than the pipeline's point capacity (status %d)", *s->h_status);
+        const int st = s->h_status[0] | (s->h_status[1] << 1);
+        if (st) return fail(LC_ECAP, "HoughLinesP: a frame holds more edge points than the pipeline's point capacity (status %d)", st);
         if (seg_count) memcpy(seg_count, s->h_segcount, sizeof(int) * s->nframes);
         if (seg_xyxy) memcpy(seg_xyxy, s->h_seg, sizeof(int32_t) * 4 * (size_t)s->nframes * s->w.seg_cap);
     }

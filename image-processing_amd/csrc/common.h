@@ -96,7 +96,8 @@ void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t
 void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowplane, int *rowcount, hipStream_t st);
 // points + Hough
 // edge points of each frame in scan order from its bit plane and per-row counts (which it clears); also
-// zeroes *status (may be null) for the Hough kernels behind it
+// zeroes the two status words (may be null) the Hough kernels behind it raise with plain stores:
+// status[0] = a frame holds more points than the list's capacity, status[1] = a vote left the accumulator
 void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, uint32_t *nz, int nz_cap, int *npoints,
                    int *status, hipStream_t st);
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,

@@ -29,6 +29,7 @@
 // gray input take the tiled kernel in kernels_edge.hip.
 #include "gate.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace lanecv {
 namespace {
@@ -126,11 +127,11 @@ template <bool BLUR, int GATE, bool INTER>   // GATE: 0 none, 1 general, 2 the l
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     __shared__ int gtab[GATE ? 512 : 1];
     if constexpr (GATE != 0) {
-        for (int i = threadIdx.x; i < 512; i += 256) gtab[i] = a.gate_tab[i];
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) gtab[i] = a.gate_tab[i];
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    const int u = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform
+    const int u = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));   // wave-uniform
     if (u >= a.nunits) return;
     const int s = u % a.nstrips;
     const int sg = (u / a.nstrips) % a.nseg;
@@ -368,7 +369,12 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.rows_per_unit = rows_per_unit;
     a.nseg = (g.H + rows_per_unit - 1) / rows_per_unit;
     a.nunits = nframes * a.nseg * a.nstrips;
-    dim3 grid((a.nunits + 3) / 4), block(256);
+    // ungated variants use no LDS and no barrier: one wavefront per workgroup, so that a unit can start wherever
+    // a single wave slot is free (LANECV_FRONT_WAVES overrides: waves per workgroup, 1..4)
+    static const char *wv_env = getenv("LANECV_FRONT_WAVES");
+    int wpg = gate ? 4 : 1;
+    if (wv_env && wv_env[0] >= '1' && wv_env[0] <= '4') wpg = wv_env[0] - '0';
+    dim3 grid((a.nunits + wpg - 1) / wpg), block(64 * wpg);
     const bool inter = gray_out || blur_out;
 #define LC_FS(B, G, I) hipLaunchKernelGGL((k_front_stream<B, G, I>), grid, block, 0, st, a)
 #define LC_FS2(B, G) do { if (inter) LC_FS(B, G, true); else LC_FS(B, G, false); } while (0)

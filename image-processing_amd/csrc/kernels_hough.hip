@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint6
                                                                int *__restrict__ npoints, int *__restrict__ status) {
     __shared__ int tot[POINTS_WAVES];
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (status && f == 0 && threadIdx.x == 0) *status = 0;   // the Hough kernels behind this one OR their error bits into it
+    if (status && f == 0 && threadIdx.x == 0) status[0] = status[1] = 0;   // the Hough kernels behind this one raise them
     const int H = g.H, TX = g.TX;
     const int rpw = (H + POINTS_WAVES - 1) / POINTS_WAVES;
     const int r0 = min(H, wv * rpw), r1 = min(H, r0 + rpw);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restric
     c.seg = seg_all + (size_t)f * seg_cap * 4;
     const int n = npoints[f];
     if (n > nz_cap) {   // the point list was truncated: refuse rather than differ
-        if (tid == 0) { seg_count[f] = 0; atomicOr(status, 1); }
+        if (tid == 0) { seg_count[f] = 0; status[0] = 1; }
         return;
     }
     for (int i = tid; i < numangle * numrho; i += 256) c.acc[i] = 0;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restric
         long long best = LLONG_MIN;
         for (int nn = lane; nn < numangle; nn += 64) {
             int r = rho_bin(j, i, tab[nn].c, tab[nn].s, c.half);
-            if ((unsigned)r >= (unsigned)numrho) { atomicOr(status, 2); continue; }
+            if ((unsigned)r >= (unsigned)numrho) { status[1] = 1; continue; }
             int val = atomicAdd(&c.acc[(size_t)nn * numrho + r], 1) + 1;
             long long key = (long long)val * 4294967296ll + (long long)(0x7FFFFFFF - nn);
             best = key > best ? key : best;
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
     const int n = npoints[f];
     if (n > nz_cap) {
-        if (tid == 0) { seg_count[f] = 0; fallback[f] = 2; atomicOr(status, 1); }
+        if (tid == 0) { seg_count[f] = 0; fallback[f] = 2; status[0] = 1; }
         return;
     }
     if (n == 0) {
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
         a_rmin[lane] = rmin;
         if (lane == 63) s_accbins = incl;
         // a table whose bins leave [0, numrho) is not OpenCV's: refuse
-        if (lane < numangle && (rmin < 0 || rmax >= numrho)) atomicOr(status, 2);
+        if (lane < numangle && (rmin < 0 || rmax >= numrho)) status[1] = 1;
     }
     __syncthreads();
     const int accbins = s_accbins, maskwords = s_maskwords;
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
             }
         }
     }
-    if (__ballot(r_over != 0 && lane < numangle) != 0 && lane == 0) atomicOr(status, 2);
+    if (__ballot(r_over != 0 && lane < numangle) != 0 && lane == 0) status[1] = 1;
     if (lane == 0) *(volatile int *)&jobs.seq = -1;   // helpers leave
     if (lane == 0) seg_count[f] = nseg;
 #ifdef LC_STAMPS
