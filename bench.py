@@ -47,7 +47,7 @@ def make_frames(seed, n, workers):
 def pmc_traffic(batch):
     """HBM bytes per k_front_stream launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
     WRITE_SIZE runs, FETCH_SIZE doubled as gfx950 needs); None when the launch shape differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "round1_v6_pmc_edge_stage.json")
+    path = os.path.join(ROOT, "profiles", "round1_v10_pmc_edge_stage.json")
     if batch != 256 or not os.path.exists(path):
         return None
     with open(path) as fh:

@@ -102,6 +102,7 @@ struct Work {
     DevBuf<uint64_t> planeS, planeW, rowplane;
     DevBuf<uint64_t> prevbits;    // masked bits last written into `masked` (pipeline slots without intermediates)
     DevBuf<uint8_t> src_in;       // frames at their source size when the pipeline resizes them first
+    DevBuf<uint8_t> rowflags;     // streaming front kernel's dirty flags of the plane rows (pipeline slots)
     DevBuf<uint32_t> wake;        // two wake-flag arrays of B * tiles words (hysteresis closure)
     DevBuf<int> rounds, rowcount, npoints, segcount, status, fallback;
     DevBuf<uint32_t> nz;
@@ -142,6 +143,14 @@ struct Work {
         if ((rc = planeS.alloc((size_t)B * g.plane_words()))) return rc;
         if ((rc = planeW.alloc((size_t)B * g.plane_words()))) return rc;
         if ((rc = rowplane.alloc((size_t)B * g.rowplane_words()))) return rc;
+        if (own_input && front_stream_supported(g) && !getenv("LANECV_FRONT_TILED")) {
+            // the streaming front kernel then stores only the strip rows that hold or held a candidate pixel
+            const size_t nf = (size_t)B * front_stream_strips(g) * H;
+            if ((rc = rowflags.alloc(nf))) return rc;
+            HIP_TRY(hipMemset(rowflags.p, 0, nf));
+            HIP_TRY(hipMemset(planeS.p, 0, sizeof(uint64_t) * (size_t)B * g.plane_words()));
+            HIP_TRY(hipMemset(planeW.p, 0, sizeof(uint64_t) * (size_t)B * g.plane_words()));
+        }
         if (own_input && !intermediates) {
             // finalize then writes only what changed since the slot's previous batch: everything starts at zero
             if ((rc = prevbits.alloc((size_t)B * g.rowplane_words()))) return rc;
@@ -830,7 +839,7 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     }
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
-                 pp->has_gate ? &pp->gate : nullptr, pp->ctx->hsv_tab.p, w.gray.p);
+                 pp->has_gate ? &pp->gate : nullptr, pp->ctx->hsv_tab.p, w.gray.p, w.rowflags.p);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
     hipStream_t ps = pp->st_post;

@@ -65,21 +65,25 @@ void launch_gate_gray(const uint8_t *bgr, size_t npix, int gray_code, const int 
 void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_t *gray, hipStream_t st);
 // streaming front kernel (kernels_front_stream.hip): interleaved 3-channel input, W % 4 == 0
 bool front_stream_supported(Geo g);
+int front_stream_strips(Geo g);     // 248-column strips per frame row
 // gate (may be null): the colour gate applied to the frame before the gray conversion; tab as above
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
-                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st);
+                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags = nullptr);
 void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st);
 // in_kind: 0 = gray bytes in, 1 = interleaved 3-channel bytes in
 // gate (may be null, 3-channel input only): colour gate in front of the gray conversion.  Frames the
 // streaming kernel cannot take go through a gated gray image first: gate_gray (nframes * W * H bytes)
 // is where it is put, and it may be the same buffer as gray_out.
+// rowflags (may be null; streaming kernel only): nframes * front_stream_strips * H bytes, all zero before the first
+// call like the two planes; with it only strip rows that hold or held a candidate pixel are stored.
 // wake: nframes * TX * TY flags, all zero on entry; the tiles that hold a weak pixel are set (launch_hysteresis
 // consumes and clears them).
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes,
                   int low, int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake,
                   uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
-                  const GateDev *gate = nullptr, const int *tab = nullptr, uint8_t *gate_gray = nullptr);
+                  const GateDev *gate = nullptr, const int *tab = nullptr, uint8_t *gate_gray = nullptr,
+                  uint8_t *rowflags = nullptr);
 // hysteresis to the fixed point: one workgroup per frame floods the tiles flagged in wake (by the front
 // kernel: those with weak pixels), then repeats over the tiles whose neighbours gained a strong border pixel
 // until a round flags none; rounds[f] receives the rounds frame f needed.  wake holds two arrays of

@@ -107,7 +107,9 @@ struct FrontArgs {
     uint64_t *planeS, *planeW;
     uint8_t *gray_out, *blur_out;
     uint32_t *wake;          // per 64x64 tile: set where a weak pixel is stored (the hysteresis kernel's work list)
+    uint8_t *rowflags;       // [frame][strip][row]: the plane bytes last stored for that strip row were not all zero; or null
     int rows_per_unit, nseg, nstrips, nunits;
+    int wg_chunk;            // logical workgroups per XCD (see the kernel)
     const int *gate_tab;     // GATE only: the HSV reciprocal tables in device memory
     GateDev gate;
 };
@@ -131,7 +133,11 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    const int u = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));   // wave-uniform
+    // Workgroups go round-robin over the 8 XCDs, each with its own L2.  Neighbouring strips share the cache lines
+    // their rows meet in (a strip row is 744 bytes, not a multiple of 128) and the plane bytes they write, so
+    // consecutive units are handed to ONE XCD: workgroup b works on logical workgroup (b % 8) * chunk + b / 8.
+    const int wgl = (int)(blockIdx.x & 7u) * a.wg_chunk + (int)(blockIdx.x >> 3);
+    const int u = __builtin_amdgcn_readfirstlane(wgl * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // wave-uniform
     if (u >= a.nunits) return;
     const int s = u % a.nstrips;
     const int sg = (u / a.nstrips) % a.nseg;
@@ -172,18 +178,32 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(fsrc + (size_t)rs * W * 3 + lane_off);
         r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
     };
-    auto store_row = [&](int n_row, uint32_t both) {
+    // Dirty tracking of the plane rows (rowflags != null; the planes then start all zero and only this kernel and the
+    // hysteresis kernel, which adds strong bits where weak ones are, write them): a strip row whose bytes were zero
+    // last time and are zero now is not stored again.  Most are, and a 31-byte store costs one or two whole sectors.
+    const size_t flag_base = ((size_t)f * a.nstrips + s) * H;
+    auto load_flag = [&](int n_row) -> uint32_t {
+        if (a.rowflags && n_row >= y0 && n_row < y1) return a.rowflags[flag_base + n_row];
+        return 1u;
+    };
+    auto store_row = [&](int n_row, uint32_t both, uint32_t pflag) {
         if (n_row >= y0 && n_row < y1) {
-            uint8_t *rowS = reinterpret_cast<uint8_t *>(a.planeS) + ((size_t)f * H + n_row) * TX * 8;
-            uint8_t *rowW = reinterpret_cast<uint8_t *>(a.planeW) + ((size_t)f * H + n_row) * TX * 8;
-            if (stores) {
-                const uint32_t wb = (both >> 8) & 0xFF;
-                rowS[bi] = (uint8_t)(both & 0xFF);
-                rowW[bi] = (uint8_t)wb;
-                if (wb) a.wake[((size_t)f * a.g.TY + (n_row >> 6)) * TX + (bi >> 3)] = 1u;
+            const bool nz = __ballot(stores && (both & 0xFFFFu) != 0) != 0;
+            const bool was = __builtin_amdgcn_readfirstlane(pflag) != 0;
+            if (nz || was) {
+                uint8_t *rowS = reinterpret_cast<uint8_t *>(a.planeS) + ((size_t)f * H + n_row) * TX * 8;
+                uint8_t *rowW = reinterpret_cast<uint8_t *>(a.planeW) + ((size_t)f * H + n_row) * TX * 8;
+                if (stores) {
+                    const uint32_t wb = (both >> 8) & 0xFF;
+                    rowS[bi] = (uint8_t)(both & 0xFF);
+                    rowW[bi] = (uint8_t)wb;
+                    if (wb) a.wake[((size_t)f * a.g.TY + (n_row >> 6)) * TX + (bi >> 3)] = 1u;
+                }
             }
+            if (a.rowflags && nz != was && lane == 0) a.rowflags[flag_base + n_row] = nz ? 1 : 0;
         }
     };
+    uint32_t pf[3] = {1u, 1u, 1u};                 // flags of the rows the next group top stores
 
     const int vend = y1 - 1 + DB + 2;
 
@@ -331,23 +351,26 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     for (; v <= vend; v += 3) {
         const uint32_t G0 = gray_row(L[0], v), G1 = gray_row(L[1], v + 1), G2 = gray_row(L[2], v + 2);
         if (v + 3 <= vend) { load_row(v + 3, L[0]); load_row(v + 4, L[1]); load_row(v + 5, L[2]); }
-        store_row(v - 3 - DB - 2, pend[0]); store_row(v - 2 - DB - 2, pend[1]); store_row(v - 1 - DB - 2, pend[2]);
+        store_row(v - 3 - DB - 2, pend[0], pf[0]); store_row(v - 2 - DB - 2, pend[1], pf[1]); store_row(v - 1 - DB - 2, pend[2], pf[2]);
+        pf[0] = load_flag(v - DB - 2); pf[1] = load_flag(v + 1 - DB - 2); pf[2] = load_flag(v + 2 - DB - 2);
         step(Phase<0>{}, v, G0);
         step(Phase<1>{}, v + 1, G1);
         step(Phase<2>{}, v + 2, G2);
     }
-    store_row(v - 3 - DB - 2, pend[0]); store_row(v - 2 - DB - 2, pend[1]); store_row(v - 1 - DB - 2, pend[2]);
+    store_row(v - 3 - DB - 2, pend[0], pf[0]); store_row(v - 2 - DB - 2, pend[1], pf[1]); store_row(v - 1 - DB - 2, pend[2], pf[2]);
 }
 
 }  // namespace
 
 bool front_stream_supported(Geo g) { return g.W % 4 == 0 && g.W >= 8; }
+int front_stream_strips(Geo g) { return (TILE * g.TX + STRIP - 1) / STRIP; }
 
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
-                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st) {
+                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags) {
     FrontArgs a;
     a.wake = wake;
+    a.rowflags = rowflags;
     a.gate_tab = tab;
     if (gate) a.gate = *gate; else a.gate = GateDev{};
     a.src = src; a.g = g; a.low = low; a.high = high;
@@ -356,7 +379,7 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     const uint32_t k0 = 2 * (code == 6 ? 3735 : 9798), k1 = 2 * 19235, k2 = 2 * (code == 6 ? 9798 : 3735);
     a.k_lo = (k0 & 255) | ((k1 & 255) << 8) | ((k2 & 255) << 16);
     a.k_hi = (k0 >> 8) | ((k1 >> 8) << 8) | ((k2 >> 8) << 16);
-    a.nstrips = (TILE * g.TX + STRIP - 1) / STRIP;   // every byte of every plane row is written
+    a.nstrips = front_stream_strips(g);              // every byte of every plane row is covered
     if (rows_per_unit <= 0) {
         // enough units to load every CU many times over (80 per CU measured best beside HoughLinesP: finer units
         // balance better around its resident workgroups), few enough to keep the 8 halo rows cheap
@@ -374,7 +397,9 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     static const char *wv_env = getenv("LANECV_FRONT_WAVES");
     int wpg = gate ? 4 : 1;
     if (wv_env && wv_env[0] >= '1' && wv_env[0] <= '4') wpg = wv_env[0] - '0';
-    dim3 grid((a.nunits + wpg - 1) / wpg), block(64 * wpg);
+    const int nwg = (a.nunits + wpg - 1) / wpg;
+    a.wg_chunk = (nwg + 7) / 8;
+    dim3 grid(8 * a.wg_chunk), block(64 * wpg);
     const bool inter = gray_out || blur_out;
 #define LC_FS(B, G, I) hipLaunchKernelGGL((k_front_stream<B, G, I>), grid, block, 0, st, a)
 #define LC_FS2(B, G) do { if (inter) LC_FS(B, G, true); else LC_FS(B, G, false); } while (0)
