@@ -161,3 +161,42 @@ def test_streaming_front_sizes(oracle, w, h, blur):
             assert (bl[i] == g).all(), i
         assert (edges[i] == oracle.canny(g, 40, 90)).all(), i
     pipe.close()
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_one_slot_many_batches(oracle, keep):
+    """One slot, batch after batch of very different frames and frame counts: the pipeline keeps state between
+    batches (it rewrites only what changed in the planes and the masked map, its flags clean themselves), so
+    every batch must still come out exactly as from a fresh pipeline."""
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h = 640, 360
+    rec = Recipe.north_star(w, h)
+    rec.threshold, rec.min_line_length = 60, 20
+    pipe = LanePipeline(w, h, rec, max_batch=4, nslots=1, seg_capacity=4096, keep_intermediates=keep)
+    adv = synth.adversarial_frames(w, h)
+    road = [synth.synth_road(w, h, seed=12, t=t) for t in range(4)]
+    batches = [
+        [adv["noise"], road[0], adv["checker2"], road[1]],
+        [road[2], adv["black"], road[3], adv["white"]],
+        [adv["black"]],
+        [road[1], adv["ramps"]],
+        [adv["noise"], adv["noise"], adv["black"], road[0]],
+        [adv["black"], adv["black"], adv["black"], adv["black"]],
+        [road[3], road[2], road[1], road[0]],
+    ]
+    for b, frames in enumerate(batches):
+        frames = np.stack(frames)
+        pipe.submit(0, frames)
+        segs = pipe.collect(0)
+        masked, acc = pipe.read(0, _abi.BUF_MASKED), pipe.read(0, _abi.BUF_ACC)
+        edges = pipe.read(0, _abi.BUF_EDGES) if keep else None
+        for i, f in enumerate(frames):
+            r = _oracle_frame(oracle, f, rec, pipe.roi)
+            assert (masked[i] == r["masked"]).all(), (b, i)
+            assert (acc[i] == r["acc"]).all(), (b, i)
+            if keep:
+                assert (edges[i] == r["edges"]).all(), (b, i)
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (b, i)
+    pipe.close()
