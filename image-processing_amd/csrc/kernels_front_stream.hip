@@ -121,17 +121,16 @@ constexpr int STRIP = 248;        // output columns of a wavefront
 template <int P> using Phase = std::integral_constant<int, P>;
 
 // GATE != 0: the colour gate of the HSV-gated script in front of the gray conversion -- a pixel outside both
-// HSV boxes counts as black, so its gray value is 0.  The two 256-entry reciprocal tables sit in LDS (2 KiB
-// a workgroup; LDS reads have their own wait counter, so they do not disturb the grouped memory traffic).
+// HSV boxes counts as black, so its gray value is 0.  The two 256-entry reciprocal tables are read from global
+// memory (2 KiB, resident in every L1): the gray conversion of a row group sits between the wait for the group's
+// pixels and the issue of the next group's loads, so the lookups of its 12 pixels go out together and cost one
+// cache round trip per group.  In LDS they would cost less per lookup, but beside a HoughLinesP workgroup a CU
+// has about 3 KiB of LDS left: one front-end workgroup per CU instead of five.
 // INTER: also store the gray (and blurred) images -- parity runs only; the variant without them keeps their
 // per-lane addresses out of the register budget.
 template <bool BLUR, int GATE, bool INTER>   // GATE: 0 none, 1 general, 2 the lane script's form (gate_keep)
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
-    __shared__ int gtab[GATE ? 512 : 1];
-    if constexpr (GATE != 0) {
-        for (int i = threadIdx.x; i < 512; i += blockDim.x) gtab[i] = a.gate_tab[i];
-        __syncthreads();
-    }
+    const int *__restrict__ gtab = a.gate_tab;
     const int lane = threadIdx.x & 63;
     // Workgroups go round-robin over the 8 XCDs, each with its own L2.  Neighbouring strips share the cache lines
     // their rows meet in (a strip row is 744 bytes, not a multiple of 128) and the plane bytes they write, so
@@ -392,10 +391,10 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.rows_per_unit = rows_per_unit;
     a.nseg = (g.H + rows_per_unit - 1) / rows_per_unit;
     a.nunits = nframes * a.nseg * a.nstrips;
-    // ungated variants use no LDS and no barrier: one wavefront per workgroup, so that a unit can start wherever
-    // a single wave slot is free (LANECV_FRONT_WAVES overrides: waves per workgroup, 1..4)
+    // no LDS and no barrier: one wavefront per workgroup, so that a unit can start wherever a single wave slot
+    // is free (LANECV_FRONT_WAVES overrides: waves per workgroup, 1..4)
     static const char *wv_env = getenv("LANECV_FRONT_WAVES");
-    int wpg = gate ? 4 : 1;
+    int wpg = 1;
     if (wv_env && wv_env[0] >= '1' && wv_env[0] <= '4') wpg = wv_env[0] - '0';
     const int nwg = (a.nunits + wpg - 1) / wpg;
     a.wg_chunk = (nwg + 7) / 8;
