@@ -465,6 +465,25 @@ int lc_and3_mask(lc_ctx *ctx, const uint8_t *src, size_t src_stride, const uint8
     return down2d(dst, dst_stride, ctx->tmp3.p, 3 * (size_t)w, h, ctx->stream);
 }
 
+int lc_add_weighted(lc_ctx *ctx, const uint8_t *a, size_t a_stride, double alpha, const uint8_t *b, size_t b_stride, double beta,
+                    double gamma, uint8_t *dst, size_t dst_stride, int row_bytes, int h) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if (!a || !b || !dst) return fail(LC_EINVAL, "addWeighted: null image pointer");
+    if (row_bytes <= 0 || h <= 0) return fail(LC_EINVAL, "addWeighted: empty image");
+    if (a_stride < (size_t)row_bytes || b_stride < (size_t)row_bytes || dst_stride < (size_t)row_bytes)
+        return fail(LC_EINVAL, "addWeighted: stride below row size");
+    if (!(alpha == alpha) || !(beta == beta) || !(gamma == gamma)) return fail(LC_EINVAL, "addWeighted: NaN weight");
+    const size_t n = (size_t)row_bytes * h;
+    if (ctx->rs_src.n < n && (rc = ctx->rs_src.alloc(n))) return rc;
+    if (ctx->rs_dst.n < n && (rc = ctx->rs_dst.alloc(n))) return rc;
+    if (ctx->tmp3.n < n && (rc = ctx->tmp3.alloc(n))) return rc;
+    if ((rc = up2d(ctx->rs_src.p, a, row_bytes, h, a_stride, ctx->stream))) return rc;
+    if ((rc = up2d(ctx->tmp3.p, b, row_bytes, h, b_stride, ctx->stream))) return rc;
+    launch_add_weighted(ctx->rs_src.p, (float)alpha, ctx->tmp3.p, (float)beta, (float)gamma, ctx->rs_dst.p, n, ctx->stream);
+    return down2d(dst, dst_stride, ctx->rs_dst.p, row_bytes, h, ctx->stream);
+}
+
 int lc_resize_linear(lc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, int channels, uint8_t *dst, int dw, int dh,
                      size_t dst_stride) {
     int rc;

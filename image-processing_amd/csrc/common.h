@@ -51,6 +51,9 @@ void hsv_tables_host(int *tab512);
 bool resize_tables_host(int sw, int sh, int dw, int dh, int *xofs, int *ia, int *yofs, int *ib);
 
 // ---- launchers (each enqueues on `st`; no synchronisation inside) ----------
+// dst = saturate(round(a * alpha + (b * beta + gamma))) over n bytes (cv::addWeighted, 8-bit)
+void launch_add_weighted(const uint8_t *a, float alpha, const uint8_t *b, float beta, float gamma, uint8_t *dst, size_t n,
+                         hipStream_t st);
 // dense frames [n][sh][sw][cn] -> [n][dh][dw][cn]; tabs = the four tables back to back in device memory
 void launch_resize_linear(const uint8_t *src, int sw, int sh, int cn, int nframes, uint8_t *dst, int dw, int dh,
                           const int *tabs, bool area2, hipStream_t st);

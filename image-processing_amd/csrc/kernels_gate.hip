@@ -173,6 +173,27 @@ __global__ __launch_bounds__(256) void k_resize_linear3x4(const uint8_t *__restr
     out[2] = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
 }
 
+// cv::addWeighted on 8-bit data: saturate(cvRound(a * alpha + (b * beta + gamma))) in float, every product and
+// sum rounded on its own; four bytes per thread
+__device__ __forceinline__ uint32_t blend1(uint32_t a, uint32_t b, float fa, float fb, float fg) {
+    const float t = __fadd_rn(__fmul_rn((float)a, fa), __fadd_rn(__fmul_rn((float)b, fb), fg));
+    const int v = __float2int_rn(fminf(fmaxf(t, -1.0f), 256.0f));
+    return (uint32_t)min(max(v, 0), 255);
+}
+__global__ __launch_bounds__(256) void k_add_weighted(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, float fa,
+                                                      float fb, float fg, uint8_t *__restrict__ dst, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const uint32_t va = *reinterpret_cast<const uint32_t *>(a + i), vb = *reinterpret_cast<const uint32_t *>(b + i);
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r |= blend1((va >> (8 * k)) & 255u, (vb >> (8 * k)) & 255u, fa, fb, fg) << (8 * k);
+        *reinterpret_cast<uint32_t *>(dst + i) = r;
+    } else {
+        for (size_t j = i; j < n; j++) dst[j] = (uint8_t)blend1(a[j], b[j], fa, fb, fg);
+    }
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -236,6 +257,11 @@ void launch_resize_linear(const uint8_t *src, int sw, int sh, int cn, int nframe
     }
     hipLaunchKernelGGL(k_resize_linear, dim3((dw + 255) / 256, dh, nframes), dim3(256), 0, st, src, sw, sh, cn, dst, dw, dh, tabs,
                        tabs + dw, tabs + 2 * dw, tabs + 2 * dw + dh, area2 ? 1 : 0);
+}
+
+void launch_add_weighted(const uint8_t *a, float alpha, const uint8_t *b, float beta, float gamma, uint8_t *dst, size_t n,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(k_add_weighted, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, a, b, alpha, beta, gamma, dst, n);
 }
 
 void launch_hsv(const uint8_t *src, size_t npix, int code, const int *tab, uint8_t *dst, hipStream_t st) {

@@ -7,7 +7,7 @@ source-compatible for these calls:
     cvtColor (COLOR_BGR2GRAY / COLOR_RGB2GRAY / COLOR_BGR2HSV / COLOR_RGB2HSV),
     resize (INTER_LINEAR, explicit dsize), GaussianBlur ((5,5), sigma 0), Canny (aperture 3, L1), fillPoly (LINE_8, shift 0),
     rectangle (filled), inRange (8UC3, integer bounds), bitwise_or, bitwise_and (optional mask),
-    HoughLinesP
+    HoughLinesP, addWeighted
 
 Same positional/keyword signatures and return conventions as cv2 (fillPoly and
 rectangle work in place and return the image; HoughLinesP returns an (N,1,4)
@@ -24,7 +24,7 @@ from . import _abi
 from ._abi import error
 
 __all__ = ["cvtColor", "resize", "GaussianBlur", "Canny", "fillPoly", "rectangle", "inRange", "bitwise_or", "bitwise_and",
-           "HoughLinesP", "hough_accumulator", "error"]
+           "HoughLinesP", "addWeighted", "hough_accumulator", "error"]
 
 COLOR_BGR2GRAY = 6
 COLOR_RGB2GRAY = 7
@@ -310,6 +310,26 @@ def HoughLinesP(image, rho, theta, threshold, lines=None, minLineLength=0, maxLi
     if n.value == 0:
         return None
     return out[:n.value].reshape(-1, 1, 4).copy()
+
+
+def addWeighted(src1, alpha, src2, beta, gamma, dst=None, dtype=-1):
+    """cv2.addWeighted on two uint8 images of one shape (the blend of the overlay the scripts draw).
+    Reference: Simple Lane Detection with OpenCV_2(images).py:50, ..._5(mp4).py:50, F1_vo_Lane_Tracking.py:196."""
+    if not isinstance(src1, _np.ndarray) or not isinstance(src2, _np.ndarray) or src1.ndim not in (2, 3):
+        raise error("addWeighted: the sources must be 2- or 3-dimensional numpy arrays")
+    a = _image(src1, "src1", src1.ndim)
+    b = _image(src2, "src2", src1.ndim)
+    if a.shape != b.shape:
+        raise error("addWeighted: sizes of the inputs differ: %s vs %s" % (a.shape, b.shape))
+    if dtype not in (-1, 0):
+        raise error("addWeighted: only an 8-bit destination is supported", _abi.LC_EUNSUPPORTED)
+    a, b = _np.ascontiguousarray(a), _np.ascontiguousarray(b)
+    h = a.shape[0]
+    row = a.size // h
+    out = _dst(dst, a.shape)
+    _abi.check(_abi.lib().lc_add_weighted(_abi.context(), _abi.ptr(a), row, float(alpha), _abi.ptr(b), row, float(beta),
+                                          float(gamma), _abi.ptr(out), row, row, h))
+    return out
 
 
 def hough_accumulator(image, rho, theta):

@@ -88,6 +88,13 @@ int lc_and3_mask(lc_ctx *ctx, const uint8_t *src, size_t src_stride, const uint8
 int lc_resize_linear(lc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, int channels,
                      uint8_t *dst, int dw, int dh, size_t dst_stride);
 
+/* cv2.addWeighted(src1, alpha, src2, beta, gamma) on 8-bit images of one size (any channel count: rows of
+ * row_bytes = width * channels bytes): dst = saturate(round(src1 * alpha + src2 * beta + gamma)), computed in
+ * float as OpenCV does.
+ * Replaces: Simple Lane Detection with OpenCV_2(images).py:50, ..._5(mp4).py:50, F1_vo_Lane_Tracking.py:196. */
+int lc_add_weighted(lc_ctx *ctx, const uint8_t *a, size_t a_stride, double alpha, const uint8_t *b, size_t b_stride,
+                    double beta, double gamma, uint8_t *dst, size_t dst_stride, int row_bytes, int h);
+
 /* cv2.GaussianBlur(src, (5,5), 0), 8UC1, BORDER_REFLECT_101.
  * Replaces: F1_vo_Lane_Tracking.py:97. */
 int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,

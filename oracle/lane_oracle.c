@@ -918,6 +918,28 @@ int lo_resize_linear(const uint8_t *src, int sw, int sh, long sstride, int cn,
 }
 
 /* ------------------------------------------------------------------ */
+/* cv::addWeighted on 8-bit data (arithm): the weights are narrowed to  */
+/* float, dst = saturate_cast<uchar>(a * alpha + (b * beta + gamma)),    */
+/* i.e. cvRound (ties to even) and clamping to [0, 255].  Each product   */
+/* and sum is rounded separately here; a build that fuses them can       */
+/* differ only where the exact value lies within a float ulp of a .5     */
+/* tie, which cannot happen for the scripts' weight pairs (0.8, 1.0),    */
+/* (1.0, 0.8) and (1.0, 0.6): n * 4/5 and n * 3/5 are never k + 1/2.     */
+/* ------------------------------------------------------------------ */
+int lo_add_weighted(const uint8_t *a, double alpha, const uint8_t *b, double beta, double gamma,
+                    uint8_t *dst, size_t n)
+{
+    if (!a || !b || !dst) return LO_EINVAL;
+    const float fa = (float)alpha, fb = (float)beta, fg = (float)gamma;
+    for (size_t i = 0; i < n; i++) {
+        const float t = (float)a[i] * fa + ((float)b[i] * fb + fg);
+        int v = t >= 255.5f ? 255 : (t <= -0.5f ? 0 : cv_round_f(t));
+        dst[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+    return LO_OK;
+}
+
+/* ------------------------------------------------------------------ */
 /* One frame through a recipe (the reference's call sequence), for the  */
 /* parity tests and the CPU baseline timing.                           */
 /*   code      LO_COLOR_*                                              */

@@ -157,6 +157,17 @@ def gate_gray(bgr, gate, gray_code=COLOR_BGR2GRAY):
     return out
 
 
+def add_weighted(a, alpha, b, beta, gamma):
+    """cv2.addWeighted(a, alpha, b, beta, gamma) on uint8 arrays of one shape."""
+    a, pa = _u8(a)
+    b, pb = _u8(b)
+    assert a.shape == b.shape
+    out = np.empty_like(a)
+    _chk(lib().lo_add_weighted(pa, C.c_double(alpha), pb, C.c_double(beta), C.c_double(gamma), out.ctypes.data_as(C.c_void_p),
+                               C.c_size_t(a.size)), "add_weighted")
+    return out
+
+
 def resize_linear(img, dsize):
     """cv2.resize(img, dsize) with INTER_LINEAR on an 8-bit image of 1 or 3 channels; dsize = (width, height)."""
     img, p = _u8(img)

@@ -90,3 +90,25 @@ def test_points_of_a_hough_recipe(oracle):
         wy, wx = np.nonzero(masked[i])
         assert (ys == wy).all() and (xs == wx).all() and len(ys) > 0
     pipe.close()
+
+
+def test_add_weighted(cv2, oracle):
+    """cv2.addWeighted with the scripts' weight pairs and a few awkward ones, 1 and 3 channels."""
+    rng = np.random.default_rng(3)
+    for shape in ((360, 640, 3), (37, 53), (1, 1, 3), (5, 7, 3)):
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = rng.integers(0, 256, shape, dtype=np.uint8)
+        b[..., 0] = 0 if a.ndim == 3 else b[..., 0]
+        for alpha, beta, gamma in ((0.8, 1.0, 0.0), (1.0, 0.8, 0.0), (1.0, 0.6, 0), (0.5, 0.5, 0.0), (1.0, 1.0, -300.0),
+                                   (-1.0, 0.25, 127.5), (2.5, 0.0, 3.0)):
+            got = cv2.addWeighted(a, alpha, b, beta, gamma)
+            assert got.shape == a.shape and got.dtype == np.uint8
+            assert (got == oracle.add_weighted(a, alpha, b, beta, gamma)).all(), (shape, alpha, beta, gamma)
+    # every pair of byte values with the weights the scripts use
+    a = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 256, axis=1)
+    b = a.T.copy()
+    for alpha, beta in ((0.8, 1.0), (1.0, 0.8), (1.0, 0.6)):
+        want = np.clip(np.floor(a.astype(np.float64) * alpha + b.astype(np.float64) * beta + 0.5), 0, 255).astype(np.uint8)
+        assert (cv2.addWeighted(a, alpha, b, beta, 0.0) == want).all()     # no exact ties: plain rounding is unambiguous
+    with pytest.raises(cv2.error):
+        cv2.addWeighted(a, 1.0, b[:5], 1.0, 0.0)

@@ -36,3 +36,19 @@ def test_against_numpy_restatement(oracle, sw, sh, dw, dh):
         got = oracle.resize_linear(img, (dw, dh))
         assert got.shape == (dh, dw) + shape[2:]
         assert (got == resize_linear_np(img, (dw, dh))).all()
+
+
+def test_add_weighted_oracle(oracle):
+    """addWeighted: every pair of byte values with the scripts' weight pairs against exact arithmetic (these
+    weights never produce a .5 tie, so float rounding order cannot matter), plus saturation."""
+    from fractions import Fraction
+    a = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 256, axis=1)
+    b = a.T.copy()
+    for alpha, beta, fa, fb in ((0.8, 1.0, Fraction(4, 5), 1), (1.0, 0.8, 1, Fraction(4, 5)), (1.0, 0.6, 1, Fraction(3, 5))):
+        got = oracle.add_weighted(a, alpha, b, beta, 0.0)
+        want = np.array([[min(255, int(x * fa + y * fb + Fraction(1, 2))) for y in range(256)] for x in range(256)], np.uint8)
+        assert (got == want).all()
+    assert oracle.add_weighted(np.array([[200]], np.uint8), 1.0, np.array([[100]], np.uint8), 1.0, 0.0)[0, 0] == 255
+    assert oracle.add_weighted(np.array([[10]], np.uint8), 1.0, np.array([[100]], np.uint8), -1.0, 0.0)[0, 0] == 0
+    assert oracle.add_weighted(np.array([[3]], np.uint8), 0.5, np.array([[0]], np.uint8), 0.0, 0.0)[0, 0] == 2    # 1.5 -> even
+    assert oracle.add_weighted(np.array([[5]], np.uint8), 0.5, np.array([[0]], np.uint8), 0.0, 0.0)[0, 0] == 2    # 2.5 -> even
