@@ -1008,7 +1008,13 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         if ((rc = s.w.init_results(segcap))) { lc_pipe_destroy(pp); return rc; }
         void *hp = nullptr;
         const size_t res_ints = s.w.res_head + (size_t)p.max_batch * segcap * 4;
-        if ((rc = lc_host_alloc_pinned(sizeof(int32_t) * res_ints, &hp))) { lc_pipe_destroy(pp); return rc; }
+        // mapped and coherent: the kernels store a batch's results into it directly (see below), and the host reads
+        // them after the batch's last event
+        if (hipHostMalloc(&hp, sizeof(int32_t) * res_ints, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            hp = nullptr;
+            (void)hipGetLastError();
+            if ((rc = lc_host_alloc_pinned(sizeof(int32_t) * res_ints, &hp))) { lc_pipe_destroy(pp); return rc; }
+        }
         s.h_res = (int32_t *)hp;
         memset(s.h_res, 0, sizeof(int32_t) * s.w.res_head);
         s.h_segcount = s.h_res; s.h_rounds = s.h_res + p.max_batch; s.h_status = s.h_res + 2 * (size_t)p.max_batch;
