@@ -979,6 +979,10 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
             if (hipStreamCreateWithPriority(&pp->st_post, hipStreamNonBlocking, hi_pri) != hipSuccess) pp->st_post = pp->st_edge;
         }
+        // with the post stream HoughLinesP starts as soon as its points are there (they are late enough: the short
+        // kernels wait for room beside the next front kernel); deferring it behind the next front kernel on top
+        // only ties it to the host's next submit
+        if (pp->st_post != pp->st_edge && !(da && da[0] >= '0' && da[0] <= '2')) pp->defer_after = 0;
     }
     pp->slots.resize(p.nslots);
     for (Slot &s : pp->slots) {
