@@ -725,6 +725,7 @@ struct Slot {
     // pinned host mirror of the slot's result block
     int32_t *h_res = nullptr;
     bool zero_copy = false;       // the kernels write the result block straight into h_res (mapped pinned memory)
+    int end_ev = 0;               // the event that marks the batch complete (index into ev)
     int *h_rounds = nullptr, *h_status = nullptr, *h_segcount = nullptr;
     int32_t *h_seg = nullptr;
 };
@@ -816,12 +817,9 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
         const bool fast = launch_ppht_fast(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
                                            p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
                                            w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls);
-        if (vote_fused) {
-            (void)hipEventRecord(s.ev[EV_VSTART], ls);
+        if (vote_fused)   // only the frames the fast kernel flagged (no events around it: every packet on this stream is on the critical path)
             launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p,
                         fast ? w.fallback.p : nullptr, ls);
-            (void)hipEventRecord(s.ev[EV_VOTE], ls);
-        }
         launch_ppht_general(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
                             p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
                             fast ? w.fallback.p : nullptr, ls);
@@ -830,11 +828,13 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
         (void)hipEventRecord(s.ev[EV_LINES], ls);
     }
+    s.end_ev = EV_LINES;
     if (!s.zero_copy) {   // one copy: counts, rounds, status and (if wanted) the segments of the n frames
         const size_t res_ints = w.res_head + (p.want_segments ? (size_t)n * w.seg_cap * 4 : 0);
         (void)hipMemcpyAsync(s.h_res, w.resblock.p, sizeof(int32_t) * res_ints, hipMemcpyDeviceToHost, ls);
+        (void)hipEventRecord(s.ev[EV_END], ls);
+        s.end_ev = EV_END;
     }
-    (void)hipEventRecord(s.ev[EV_END], ls);
 }
 
 // from_host: the frames were just queued for copy on st_up (EV_START is recorded there)
@@ -1092,7 +1092,7 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
     if (pipe->deferred == slot) { enqueue_lines(pipe, *s, nullptr); pipe->deferred = -1; }
-    HIP_TRY(hipEventSynchronize(s->ev[EV_END]));
+    HIP_TRY(hipEventSynchronize(s->ev[s->end_ev]));
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
     if (p.want_segments) {
@@ -1165,12 +1165,12 @@ int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms) {
         case LC_STAGE_UPLOAD: a = EV_START; b = EV_UPLOADED; break;
         case LC_STAGE_EDGE: a = EV_ESTART; b = EV_EDGE; break;
         case LC_STAGE_POINTS: a = EV_EDGE; b = EV_POINTS; break;
-        case LC_STAGE_VOTE:   // with segments wanted: only the launch for the frames HoughLinesP flagged
-            a = (pipe->p.want_accumulator && pipe->p.want_segments) ? EV_VSTART : EV_POINTS;
-            b = EV_VOTE;
+        case LC_STAGE_VOTE:   // with segments wanted the accumulator comes out of the HoughLinesP kernel: counted under LINES
+            if (pipe->p.want_accumulator && pipe->p.want_segments) { *ms = 0.f; return LC_OK; }
+            a = EV_POINTS; b = EV_VOTE;
             break;
         case LC_STAGE_LINES: a = EV_LSTART; b = EV_LINES; break;
-        case LC_STAGE_TOTAL: a = EV_START; b = EV_END; break;
+        case LC_STAGE_TOTAL: a = EV_START; b = s->end_ev; break;
         case LC_STAGE_FRONT: a = EV_ESTART; b = EV_FRONT; break;
         case LC_STAGE_HYST: a = EV_FRONT; b = EV_HYST; break;
         case LC_STAGE_FINAL: a = EV_HYST; b = EV_EDGE; break;
