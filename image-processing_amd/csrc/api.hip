@@ -817,12 +817,12 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
         const bool fast = launch_ppht_fast(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
                                            p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
                                            w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls);
-        if (vote_fused)   // only the frames the fast kernel flagged (no events around it: every packet on this stream is on the critical path)
-            launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p,
-                        fast ? w.fallback.p : nullptr, ls);
+        // one launch for the frames the fast kernel flagged: their full-vote accumulator first (the general kernel
+        // permutes the point list), then HoughLinesP with all state in global memory.  No events in between: every
+        // packet on this stream is on the critical path.
         launch_ppht_general(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
                             p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
-                            fast ? w.fallback.p : nullptr, ls);
+                            fast ? w.fallback.p : nullptr, ls, vote_fused ? w.acc_full.p : nullptr);
         (void)hipEventRecord(s.ev[EV_LINES], ls);
     } else {
         (void)hipEventRecord(s.ev[EV_LSTART], ls);

@@ -116,7 +116,7 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
 void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                          const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
                          int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, const int *flags,
-                         hipStream_t st);
+                         hipStream_t st, int32_t *vote_acc = nullptr);   // vote_acc: also the full-vote accumulator of the frames flagged with bit 1
 // polygons
 struct PolyEdgeDev { int y0, y1; long long x, dx; };
 struct LineDev { int x0, y0, count, vert, dmaj, dmin, dmajor_len, dminor_len; };

@@ -91,18 +91,15 @@ __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint6
 // bin of an angle (rho moves by less than one bin per pixel) and plain per-lane atomics would serialise
 // on that address.  Each run of equal bins is therefore added once, by its first lane, with the run's
 // length: a DPP shift finds the run starts, a ballot and a count of trailing zeros their lengths.
-__global__ __launch_bounds__(256) void k_vote(const uint32_t *__restrict__ nz, int nz_cap, const int *__restrict__ npoints,
-                                               const AngleEntry *__restrict__ tab, int numangle, int numrho, int apg,
-                                               int32_t *__restrict__ acc, const int *__restrict__ flags) {
-    extern __shared__ int lacc[];
-    const int f = blockIdx.y;
-    if (flags && !(flags[f] & 2)) return;   // HoughLinesP already produced this frame's accumulator
+// (a_first, a_step: the angle groups this workgroup takes are a_first, a_first + a_step, ...)
+__device__ __forceinline__ void vote_frame(int *lacc, int f, int a_first, int a_step, const uint32_t *__restrict__ nz, int nz_cap,
+                                           const int *__restrict__ npoints, const AngleEntry *__restrict__ tab, int numangle,
+                                           int numrho, int apg, int32_t *__restrict__ acc) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
     const int n = min(npoints[f], nz_cap);
     const int half = (numrho - 1) / 2;
     const uint32_t *pts = nz + (size_t)f * nz_cap;
-    // a block takes the angle groups blockIdx.x, blockIdx.x + gridDim.x, ... (all of them in the flagged launch)
-    for (int a0 = blockIdx.x * apg; a0 < numangle; a0 += gridDim.x * apg) {
+    for (int a0 = a_first * apg; a0 < numangle; a0 += a_step * apg) {
         const int na = min(apg, numangle - a0);
         __syncthreads();
         for (int i = tid; i < na * numrho; i += nt) lacc[i] = 0;
@@ -126,6 +123,17 @@ __global__ __launch_bounds__(256) void k_vote(const uint32_t *__restrict__ nz, i
         int32_t *out = acc + ((size_t)f * numangle + a0) * numrho;
         for (int i = tid; i < na * numrho; i += nt) out[i] = lacc[i];
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_vote(const uint32_t *__restrict__ nz, int nz_cap, const int *__restrict__ npoints,
+                                               const AngleEntry *__restrict__ tab, int numangle, int numrho, int apg,
+                                               int32_t *__restrict__ acc, const int *__restrict__ flags) {
+    extern __shared__ int lacc[];
+    const int f = blockIdx.y;
+    if (flags && !(flags[f] & 2)) return;   // HoughLinesP already produced this frame's accumulator
+    // a block takes the angle groups blockIdx.x, blockIdx.x + gridDim.x, ...
+    vote_frame(lacc, f, blockIdx.x, gridDim.x, nz, nz_cap, npoints, tab, numangle, numrho, apg, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -585,9 +593,14 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restric
                                                       int32_t *__restrict__ acc_all, int threshold, int line_length,
                                                       int line_gap, int32_t *__restrict__ seg_all, int seg_cap,
                                                       int *__restrict__ seg_count, int *__restrict__ status,
-                                                      const int *__restrict__ fallback) {
+                                                      const int *__restrict__ fallback, int32_t *__restrict__ vote_acc,
+                                                      int vote_apg) {
+    extern __shared__ int lacc_vote[];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    if (fallback && !(fallback[f] & 1)) return;
+    const int fl = fallback ? fallback[f] : 3;
+    // the full-vote accumulator of a frame the fast kernel could not do, before this kernel permutes the point list
+    if (vote_acc && (fl & 2)) vote_frame(lacc_vote, f, 0, 1, nz_all, nz_cap, npoints, tab, numangle, numrho, vote_apg, vote_acc);
+    if (!(fl & 1)) return;
     uint32_t *nz = nz_all + (size_t)f * nz_cap;
     Ppht c;
     c.W = g.W; c.H = g.H; c.TX = g.TX; c.numangle = numangle; c.numrho = numrho; c.half = (numrho - 1) / 2;
@@ -1041,16 +1054,21 @@ void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, 
     hipLaunchKernelGGL(k_points, dim3(nframes), dim3(64 * POINTS_WAVES), 0, st, g, rowplane, rowcount, nz, nz_cap, npoints, status);
 }
 
-void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
-                 int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st) {
-    (void)g;
-    // angle rows per block: what fits 6 KiB of LDS, at least one.  Small on purpose: the kernel then shares
-    // CUs with the HoughLinesP kernel of another batch, which leaves only a few KiB of LDS free.
+// angle rows per workgroup of the vote: what fits 6 KiB of LDS, at least one.  Small on purpose: the kernel then
+// shares CUs with the HoughLinesP kernel of another batch, which leaves only a few KiB of LDS free.
+static int vote_apg(int numangle, int numrho, int &groups) {
     int apg = (6 * 1024) / (numrho * 4);
     if (apg < 1) apg = 1;
     if (apg > numangle) apg = numangle;
-    int groups = (numangle + apg - 1) / apg;
-    apg = (numangle + groups - 1) / groups;
+    groups = (numangle + apg - 1) / apg;
+    return (numangle + groups - 1) / groups;
+}
+
+void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
+                 int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st) {
+    (void)g;
+    int groups;
+    const int apg = vote_apg(numangle, numrho, groups);
     size_t lds = (size_t)apg * numrho * 4;
     static size_t attr_set = 0;
     if (lds > 64 * 1024 && lds > attr_set) {
@@ -1090,9 +1108,20 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
 void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                          const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
                          int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, const int *flags,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(k_ppht_general, dim3(nframes), dim3(256), 0, st, g, nz, nz_cap, npoints, rowplane, tab, numangle, numrho,
-                       acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags);
+                         hipStream_t st, int32_t *vote_acc) {
+    int groups, apg = 0;
+    size_t lds = 0;
+    if (vote_acc) {
+        apg = vote_apg(numangle, numrho, groups);
+        lds = (size_t)apg * numrho * 4;
+        static size_t attr_set = 0;
+        if (lds > 64 * 1024 && lds > attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_general), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = lds;
+        }
+    }
+    hipLaunchKernelGGL(k_ppht_general, dim3(nframes), dim3(256), lds, st, g, nz, nz_cap, npoints, rowplane, tab, numangle, numrho,
+                       acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, vote_acc, apg);
 }
 
 #ifdef LC_STAMPS
