@@ -161,8 +161,6 @@ def main():
         front_bytes = 3.25 * W * H * batch
         front_ms = mean["front"]
         achieved = front_bytes / (front_ms * 1e-3) / 1e9
-        # whole edge stage (front + hysteresis + finalize): 3 B/px in, the 1 B/px masked edge map out
-        edge_ms = mean["front"] + mean["hyst"] + mean["final"]
         stage_bytes = 4.0 * W * H * batch
         out = {
             "metric": "1080p lane-pipeline frames/sec", "value": round(fps, 1), "unit": "frames/s",
@@ -181,10 +179,6 @@ def main():
                          "note": "duration = HIP events around the kernel on the stream it runs on, inside the timed region "
                                  "(HoughLinesP of the previous batch runs beside it); traffic = FETCH_SIZE (x2, gfx950) + "
                                  "WRITE_SIZE per launch from the committed rocprofv3 PMC passes of the same launch shape"},
-            "roofline_edge_stage": {"kernels": "k_front_stream + k_hysteresis + k_finalize_sparse",
-                                    "algorithmic_bytes_per_launch": stage_bytes, "launch_ms": round(edge_ms, 4),
-                                    "achieved": round(stage_bytes / (edge_ms * 1e-3) / 1e9, 1),
-                                    "frac": round(stage_bytes / (edge_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "stage_ms": {k: round(v, 4) for k, v in mean.items()},
             "segments_frame0": int(cnt[0]), "gathered_ranks": len(gathered), "hyst_closure_rounds_max_total": list(pipe.hyst_rounds(0)),
         }
@@ -196,6 +190,14 @@ def main():
             pipe.wait(0)
             excl.append({n: pipe.stage_ms(0, i) for n, i in stage_names.items()})
         em = {n: float(np.median([s[n] for s in excl])) for n in stage_names}
+        # whole edge stage (front + hysteresis + finalize): 3 B/px in, the 1 B/px masked edge map out.  Taken from the
+        # exclusive run: in the timed region its short kernels sit on a stream of their own and their event-to-event
+        # times are mostly waiting for room beside the next batch's front kernel.
+        edge_x = em["front"] + em["hyst"] + em["final"]
+        out["roofline_edge_stage"] = {"kernels": "k_front_stream + k_hysteresis + k_finalize_sparse, one batch in flight",
+                                      "algorithmic_bytes_per_launch": stage_bytes, "launch_ms": round(edge_x, 4),
+                                      "achieved": round(stage_bytes / (edge_x * 1e-3) / 1e9, 1),
+                                      "frac": round(stage_bytes / (edge_x * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out["roofline_exclusive"] = {"kernel": "k_front_stream<true, 0, false>, nothing else on the GPU", "launch_ms": round(em["front"], 4),
                                      "achieved": round(front_bytes / (em["front"] * 1e-3) / 1e9, 1),
                                      "frac": round(front_bytes / (em["front"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
