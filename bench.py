@@ -54,6 +54,41 @@ def pmc_traffic(batch):
         return round(json.load(fh)["kernels"]["k_front_stream<true, 0, false>"]["traffic_bytes"])
 
 
+def vote_rates(dev_ptr, batch, device):
+    """LDS-atomic throughput of the Hough vote: the same frames through a pipeline that stops at the full-vote
+    accumulator (k_vote on every frame; in the timed recipe HoughLinesP's kernel produces the accumulator on the
+    side), one batch in flight, against this GPU's LDS atomic-add rate measured by the library's probe kernel."""
+    import numpy as np
+    from lanecv import _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    rec = Recipe.north_star(W, H)
+    rec.segments = False
+    pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=1, device=device)
+    ms = []
+    for _ in range(6):
+        pipe.submit_device(0, dev_ptr, batch)
+        pipe.wait(0)
+        ms.append(pipe.stage_ms(0, _abi.STAGE_VOTE))
+    ms = float(np.median(ms[1:]))
+    points = int(pipe.read(0, _abi.BUF_NPOINTS).astype(np.int64).sum())
+    numangle, numrho = pipe.numangle, pipe.numrho
+    pipe.close()
+    votes = float(points) * numangle
+    peak = {"own_word": _abi.lds_atomic_rate(1, False, device), "run_of_8": _abi.lds_atomic_rate(8, False, device),
+            "one_word_per_wave": _abi.lds_atomic_rate(64, False, device), "random_words": _abi.lds_atomic_rate(0, False, device),
+            "own_word_returning": _abi.lds_atomic_rate(1, True, device),
+            "random_words_returning": _abi.lds_atomic_rate(0, True, device)}
+    ach = votes / (ms * 1e-3) / 1e9
+    return {"kernel": "k_vote, one batch in flight", "launch_ms": round(ms, 4), "edge_points_per_launch": points,
+            "votes_per_launch": votes, "accumulator": [numangle, numrho],
+            "achieved": round(ach, 1), "unit": "1e9 votes/s (LDS atomic increments the accumulator receives: points x angles)",
+            "lds_atomic_peak": {k: round(v, 1) for k, v in peak.items()},
+            "frac_of_own_word_peak": round(ach / peak["own_word"], 4),
+            "note": "peaks = int32 LDS atomic adds per second of the probe kernel (lc_lds_atomic_rate) on this GPU, 8 "
+                    "workgroups of 256 lanes per CU, by address pattern; k_vote issues one lane-level atomic per vote (the lanes of a wavefront "
+                    "take stretches of the sorted point list that lie n/64 points apart, so that they rarely meet in a bin)"}
+
+
 def cpu_baseline(frames, rec, roi, threads):
     """The CPU oracle (a scalar C port of the OpenCV arithmetic), frame-parallel over `threads` host threads."""
     from concurrent.futures import ThreadPoolExecutor
@@ -202,6 +237,8 @@ def main():
                                      "achieved": round(front_bytes / (em["front"] * 1e-3) / 1e9, 1),
                                      "frac": round(front_bytes / (em["front"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "stage_ms": {k: round(v, 4) for k, v in em.items()}}
+
+        out["vote"] = vote_rates(ptr, batch, local_rank)
 
         if not args.no_streaming:
             # PCIe-inclusive rate: pinned host ring -> hipMemcpyAsync -> pipeline, slots overlapped (never `value`)

@@ -171,6 +171,7 @@ struct Work {
         return LC_OK;
     }
     int init_points(int cap) {
+        cap = (cap + 3) & ~3;     // every frame's list starts on a 16-byte boundary (the vote loads four points at once)
         nz_cap = cap;
         return nz.alloc((size_t)B * cap);
     }
@@ -482,6 +483,26 @@ int lc_add_weighted(lc_ctx *ctx, const uint8_t *a, size_t a_stride, double alpha
     if ((rc = up2d(ctx->tmp3.p, b, row_bytes, h, b_stride, ctx->stream))) return rc;
     launch_add_weighted(ctx->rs_src.p, (float)alpha, ctx->tmp3.p, (float)beta, (float)gamma, ctx->rs_dst.p, n, ctx->stream);
     return down2d(dst, dst_stride, ctx->rs_dst.p, row_bytes, h, ctx->stream);
+}
+
+int lc_lds_atomic_rate(lc_ctx *ctx, int run, int returning, double *gadds_per_s) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if (!gadds_per_s) return fail(LC_EINVAL, "lds_atomic_rate: null result pointer");
+    if (run < 0 || run > 64) return fail(LC_EINVAL, "lds_atomic_rate: run length %d outside [0, 64]", run);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    const int blocks = prop.multiProcessorCount * 8;   // eight 256-thread workgroups (8 KiB of LDS each) per CU
+    DevBuf<int> sink;
+    if ((rc = sink.alloc(blocks))) return rc;
+    float ms = 0.f;
+    double adds = 0;
+    // slow patterns serialise inside the LDS unit: fewer iterations keep every launch in the millisecond range
+    const int iters = run == 1 ? 4000 : 1000;
+    if (lds_atomic_probe(run, returning != 0, blocks, iters, sink.p, ctx->stream, &ms, &adds) || !(ms > 0.f))
+        return fail(LC_EHIP, "lds_atomic_rate: probe launch failed: %s", hipGetErrorString(hipGetLastError()));
+    *gadds_per_s = adds / (ms * 1e-3) / 1e9;
+    return LC_OK;
 }
 
 int lc_resize_linear(lc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, int channels, uint8_t *dst, int dw, int dh,

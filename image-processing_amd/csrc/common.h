@@ -109,6 +109,8 @@ void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, 
                    int *status, hipStream_t st);
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
                  int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st);
+// LDS atomic-add rate probe (kernels_probe.hip): best of three launches; 0 on success
+int lds_atomic_probe(int run, bool returning, int blocks, int iters, int *sink, hipStream_t st, float *ms, double *adds);
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,

@@ -87,41 +87,81 @@ __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint6
 }
 
 // full-vote accumulator: block (group, frame) owns `apg` angle rows in LDS.
-// The points come sorted by row and column, so neighbouring lanes of a wavefront mostly hit the same
-// bin of an angle (rho moves by less than one bin per pixel) and plain per-lane atomics would serialise
-// on that address.  Each run of equal bins is therefore added once, by its first lane, with the run's
-// length: a DPP shift finds the run starts, a ballot and a count of trailing zeros their lengths.
-// (a_first, a_step: the angle groups this workgroup takes are a_first, a_first + a_step, ...)
+// The points come sorted by row and column, and rho moves by less than one bin per pixel: neighbours of the
+// list mostly vote for the same bin of an angle, and lanes that add to one LDS word in one instruction are
+// served one after the other.  The 64 lanes of a wavefront therefore take 64 equal stretches of the whole list
+// (n / 64 points each, split between the workgroup's wavefronts): lanes are then many rows apart and their
+// votes spread over the angle's row, while a lane's own consecutive points, which do share bins, arrive in
+// different instructions.  Points are taken four at a time, their coordinates converted to float once for all
+// angles of the group.  A vote is branch-free: two multiplies and an add (each rounded on its own, as
+// OpenCV's float expression is), round-to-nearest-even by adding 1.5 * 2^23 (exact for |rho| < 2^22; the
+// result's low bits are the integer), one subtraction that also adds the row's centre, an unsigned minimum that
+// sends anything outside the row to a spare word behind it, and the atomic add.  The ragged ends of the
+// stretches go point by point with absent points masked off (adds of 0 for them would all meet in one word).
+// LDS: apg rows of numrho + 1 words.  (a_first, a_step: the angle groups this workgroup takes are a_first,
+// a_first + a_step, ...)
 __device__ __forceinline__ void vote_frame(int *lacc, int f, int a_first, int a_step, const uint32_t *__restrict__ nz, int nz_cap,
                                            const int *__restrict__ npoints, const AngleEntry *__restrict__ tab, int numangle,
                                            int numrho, int apg, int32_t *__restrict__ acc) {
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int n = min(npoints[f], nz_cap);
-    const int half = (numrho - 1) / 2;
+    const int half = (numrho - 1) / 2, stride = numrho + 1;
     const uint32_t *pts = nz + (size_t)f * nz_cap;
+    // a lane's stretch and a wavefront's part of it, both multiples of four points: with a list that starts on a
+    // 16-byte boundary a lane's four points are one 16-byte load (a wavefront's loads touch 64 different cache lines
+    // either way; single-word loads touch them four times)
+    const int S64 = ((n + 63) / 64 + 3) & ~3, nw = nt >> 6, per = ((S64 + nw - 1) / nw + 3) & ~3;
+    const bool vec = ((reinterpret_cast<uintptr_t>(pts) & 15) == 0);
+    const int w0 = (tid >> 6) * per, wend = min(w0 + per, S64);
+    const uint32_t unbias = 0x4B400000u - (uint32_t)half;                       // bits of 1.5 * 2^23, less the row's centre
     for (int a0 = a_first * apg; a0 < numangle; a0 += a_step * apg) {
         const int na = min(apg, numangle - a0);
         __syncthreads();
-        for (int i = tid; i < na * numrho; i += nt) lacc[i] = 0;
+        for (int i = tid; i < na * stride; i += nt) lacc[i] = 0;
         __syncthreads();
-        for (int p0 = tid - lane; p0 < n; p0 += nt) {       // wave-uniform trip count: 64 consecutive points per wavefront
-            const int p = p0 + lane;
-            const bool valid = p < n;
-            const uint32_t pt = valid ? pts[p] : 0u;
-            const int x = pt & 0xFFFF, y = pt >> 16;
-            for (int a = 0; a < na; a++) {
-                const int r = rho_bin(x, y, tab[a0 + a].c, tab[a0 + a].s, half);
-                const int key = (valid && (unsigned)r < (unsigned)numrho) ? r : -1;
-                const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138, 0xF, 0xF, false);   // lane - 1's key; lane 0 gets -2
-                const uint64_t starts = __ballot(key != prev);
-                const uint64_t above = lane == 63 ? 0ull : (starts >> (lane + 1));
-                const int len = above ? __builtin_ctzll(above) + 1 : 64 - lane;                 // lanes to the next run start
-                if (key != prev && key >= 0) atomicAdd(&lacc[a * numrho + key], len);
+        for (int i = w0; i < wend; i += 4) {
+            const int p = (tid & 63) * S64 + i;
+            const int cnt = min(4, wend - i);
+            if (cnt == 4 && p + 3 < n) {                 // all lanes but those at the very end of the list
+                float fx[4], fy[4];
+                uint32_t pt[4];
+                if (vec) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(pts + p);
+                    pt[0] = q.x; pt[1] = q.y; pt[2] = q.z; pt[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pt[k] = pts[p + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    fx[k] = (float)(pt[k] & 0xFFFF);
+                    fy[k] = (float)(pt[k] >> 16);
+                }
+                for (int a = 0; a < na; a++) {
+                    const float c = tab[a0 + a].c, sn = tab[a0 + a].s;
+                    int *row = lacc + a * stride;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float t = __fadd_rn(__fadd_rn(__fmul_rn(fx[k], c), __fmul_rn(fy[k], sn)), 12582912.0f);
+                        atomicAdd(&row[min(__float_as_uint(t) - unbias, (uint32_t)numrho)], 1);
+                    }
+                }
+            } else {                                     // ragged end of the stretches: point by point, absent ones masked off
+                for (int k = 0; k < cnt; k++) {
+                    if (p + k >= n) continue;
+                    const uint32_t pt = pts[p + k];
+                    const float fx = (float)(pt & 0xFFFF), fy = (float)(pt >> 16);
+                    for (int a = 0; a < na; a++) {
+                        const float t = __fadd_rn(__fadd_rn(__fmul_rn(fx, tab[a0 + a].c), __fmul_rn(fy, tab[a0 + a].s)), 12582912.0f);
+                        atomicAdd(&lacc[a * stride + min(__float_as_uint(t) - unbias, (uint32_t)numrho)], 1);
+                    }
+                }
             }
         }
         __syncthreads();
         int32_t *out = acc + ((size_t)f * numangle + a0) * numrho;
-        for (int i = tid; i < na * numrho; i += nt) out[i] = lacc[i];
+        for (int a = 0; a < na; a++)
+            for (int i = tid; i < numrho; i += nt) out[a * numrho + i] = lacc[a * stride + i];
     }
     __syncthreads();
 }
@@ -1056,8 +1096,8 @@ void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, 
 
 // angle rows per workgroup of the vote: what fits 6 KiB of LDS, at least one.  Small on purpose: the kernel then
 // shares CUs with the HoughLinesP kernel of another batch, which leaves only a few KiB of LDS free.
-static int vote_apg(int numangle, int numrho, int &groups) {
-    int apg = (6 * 1024) / (numrho * 4);
+static int vote_apg(int numangle, int numrho, int &groups, int budget = 6 * 1024) {
+    int apg = budget / ((numrho + 1) * 4);
     if (apg < 1) apg = 1;
     if (apg > numangle) apg = numangle;
     groups = (numangle + apg - 1) / apg;
@@ -1068,8 +1108,12 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
                  int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st) {
     (void)g;
     int groups;
-    const int apg = vote_apg(numangle, numrho, groups);
-    size_t lds = (size_t)apg * numrho * 4;
+    // on its own (no flags) the kernel does not share CUs with HoughLinesP: 16 KiB of rows per workgroup (eight
+    // workgroups fill a CU's wave slots), so that a workgroup's pass over the frame's points serves more angles;
+    // 32 KiB was slower (0.054 against 0.040 ms for 256 1080p frames), 8 KiB too (0.079)
+    const int budget = 16 * 1024;
+    const int apg = flags ? vote_apg(numangle, numrho, groups) : vote_apg(numangle, numrho, groups, budget);
+    size_t lds = (size_t)apg * (numrho + 1) * 4;
     static size_t attr_set = 0;
     if (lds > 64 * 1024 && lds > attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1113,7 +1157,7 @@ void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int
     size_t lds = 0;
     if (vote_acc) {
         apg = vote_apg(numangle, numrho, groups);
-        lds = (size_t)apg * numrho * 4;
+        lds = (size_t)apg * (numrho + 1) * 4;
         static size_t attr_set = 0;
         if (lds > 64 * 1024 && lds > attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_general), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -27,7 +27,7 @@ STAGE_UPLOAD, STAGE_EDGE, STAGE_POINTS, STAGE_VOTE, STAGE_LINES, STAGE_TOTAL, ST
 SYMBOLS = [
     "lc_version", "lc_last_error", "lc_create", "lc_destroy", "lc_host_alloc_pinned", "lc_host_free",
     "lc_cvt_gray", "lc_cvt_hsv", "lc_in_range3", "lc_or", "lc_and3_mask", "lc_resize_linear", "lc_add_weighted", "lc_gaussian5", "lc_canny", "lc_fill_poly", "lc_rectangle_filled", "lc_and",
-    "lc_hough_geometry", "lc_hough_accum", "lc_hough_lines_p",
+    "lc_hough_geometry", "lc_hough_accum", "lc_hough_lines_p", "lc_lds_atomic_rate",
     "lc_pipe_create", "lc_pipe_destroy", "lc_pipe_submit_host", "lc_pipe_submit_device", "lc_pipe_wait",
     "lc_pipe_read", "lc_pipe_read_points", "lc_pipe_stage_ms", "lc_pipe_input_device_ptr", "lc_pipe_upload", "lc_pipe_hyst_rounds",
 ]
@@ -78,6 +78,7 @@ def lib():
         L.lc_hough_geometry.argtypes = [i, i, d, d, C.POINTER(i), C.POINTER(i)]
         L.lc_hough_accum.argtypes = [vp, vp, i, i, sz, d, d, vp, i, C.POINTER(i), C.POINTER(i)]
         L.lc_hough_lines_p.argtypes = [vp, vp, i, i, sz, d, d, i, d, d, vp, i, C.POINTER(i)]
+        L.lc_lds_atomic_rate.argtypes = [vp, i, i, C.POINTER(d)]
         L.lc_pipe_create.argtypes = [vp, C.POINTER(PipeParams), C.POINTER(vp)]
         L.lc_pipe_destroy.argtypes = [vp]
         L.lc_pipe_submit_host.argtypes = [vp, i, vp, i]
@@ -112,6 +113,14 @@ def context(device=None):
         check(lib().lc_create(device, C.byref(h)))
         c = _ctx[device] = h
     return c
+
+
+def lds_atomic_rate(run=1, returning=False, device=None):
+    """1e9 lane-level int32 LDS atomic adds per second this GPU sustains for the given address pattern
+    (run = lanes sharing a word, 0 = pseudo-random words); the ceiling the vote kernels are reported against."""
+    v = C.c_double()
+    check(lib().lc_lds_atomic_rate(context(device), int(run), int(bool(returning)), C.byref(v)))
+    return v.value
 
 
 def ptr(a):

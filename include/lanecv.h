@@ -136,6 +136,12 @@ int lc_hough_accum(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride,
                    double rho, double theta, int32_t *acc, int acc_capacity,
                    int *numangle, int *numrho);
 
+/* Measurement aid with no counterpart in the reference: the rate at which this GPU performs int32 atomic adds
+ * in LDS, in 1e9 lane-level adds per second, for the ceiling the vote kernels are reported against.
+ * run = 1: every lane its own word; run = r (2..64): r neighbouring lanes share a word; run = 0: pseudo-random
+ * words.  returning != 0 measures the form that hands the old value back (HoughLinesP's vote). */
+int lc_lds_atomic_rate(lc_ctx *ctx, int run, int returning, double *gadds_per_s);
+
 /* cv2.HoughLinesP(image, rho, theta, threshold, minLineLength=, maxLineGap=).
  * out receives up to `capacity` rows of (x1, y1, x2, y2) in OpenCV's detection
  * order; *n is the number found (LC_ECAP if it exceeds capacity).

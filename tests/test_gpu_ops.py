@@ -265,3 +265,14 @@ def test_errors(cv2):
         cv2.bitwise_and(c, c, mask=np.zeros((5, 5), np.uint8))
     with pytest.raises(cv2.error):
         cv2.bitwise_or(g, np.zeros((5, 5), np.uint8))
+
+
+def test_lds_atomic_rate_probe():
+    """The measurement aid behind the vote figures: plausible rates, ordered as the address patterns suggest."""
+    from lanecv import _abi
+    own = _abi.lds_atomic_rate(1, False)
+    one = _abi.lds_atomic_rate(64, False)
+    assert own > 100.0 and one > 1.0          # 1e9 adds/s; a whole MI355X does thousands with every lane on its own word
+    assert own >= one * 0.99
+    with pytest.raises(_abi.error):
+        _abi.lds_atomic_rate(65, False)
