@@ -778,7 +778,10 @@ struct lc_pipe {
     //   st_lines  HoughLinesP and the copy of the batch's results.  One workgroup per frame that wants most of a
     //             CU's LDS: high priority for the same reason.
     hipStream_t st_up = nullptr, st_edge = nullptr, st_post = nullptr, st_lines = nullptr;
-    // Second HoughLinesP stream (diagnostics, LANECV_LINES_STREAMS=2): batches alternate between the two.
+    // Second HoughLinesP stream, never created: kept as the place where more of them would go.  Batches smaller than
+    // the number of CUs would profit (HoughLinesP is one sequential workgroup per frame, a batch of 32 frames leaves
+    // 7/8 of the chip idle for 0.44 ms), but with three or more HoughLinesP streams on top of the other three the
+    // pipeline hung on this runtime (more streams than hardware queues, waits between streams that share one).
     hipStream_t st_lines2 = nullptr;
     unsigned lines_turn = 0;
 

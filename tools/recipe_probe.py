@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "image-processing_amd"))
 name = sys.argv[1]
 W, H, B, STEPS = (int(v) for v in (sys.argv[2:6] + ["1920", "1080", "64", "40"][len(sys.argv) - 2:]))
 SW, SH = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (W, H)
+NS = int(os.environ.get("PROBE_SLOTS", "3"))     # batches in flight
 import torch  # noqa: E402  (before liblanecv.so: both must share one HIP runtime)
 from lanecv import _abi, synth  # noqa: E402
 from lanecv.pipeline import LanePipeline, Recipe  # noqa: E402
@@ -21,7 +22,7 @@ from lanecv.pipeline import LanePipeline, Recipe  # noqa: E402
 rec = getattr(Recipe, name)(W, H)
 base = np.stack([synth.synth_road(SW, SH, seed=100, t=t) for t in range(min(B, 16))])
 frames = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
-pipe = LanePipeline(W, H, rec, max_batch=B, nslots=3, seg_capacity=64, src_size=(SW, SH))
+pipe = LanePipeline(W, H, rec, max_batch=B, nslots=NS, seg_capacity=64, src_size=(SW, SH))
 dev = torch.from_numpy(frames).cuda()
 torch.cuda.synchronize()
 stage = {"front": _abi.STAGE_FRONT, "hyst": _abi.STAGE_HYST, "final": _abi.STAGE_FINAL, "points": _abi.STAGE_POINTS,
@@ -31,8 +32,8 @@ stage = {"front": _abi.STAGE_FRONT, "hyst": _abi.STAGE_HYST, "final": _abi.STAGE
 def run(steps, acc=None):
     fl = []
     for k in range(steps):
-        s = k % 3
-        if len(fl) == 3:
+        s = k % NS
+        if len(fl) == NS:
             d = fl.pop(0)
             pipe.wait(d)
             if acc is not None:
@@ -55,7 +56,7 @@ for _ in range(5):
     pipe.wait(0)
     ex.append({n: pipe.stage_ms(0, i) for n, i in stage.items()})
 seg, cnt = pipe.wait(0) if False else (None, None)
-print(json.dumps({"recipe": name, "w": W, "h": H, "src": [SW, SH], "batch": B, "fps": round(STEPS * B / dt, 1),
+print(json.dumps({"recipe": name, "w": W, "h": H, "src": [SW, SH], "batch": B, "slots": NS, "fps": round(STEPS * B / dt, 1),
                   "ms_per_batch": round(dt / STEPS * 1e3, 4),
                   "stage_ms_in_flight": {n: round(float(np.mean([s[n] for s in st])), 4) for n in stage},
                   "stage_ms_exclusive": {n: round(float(np.median([s[n] for s in ex])), 4) for n in stage}}))
