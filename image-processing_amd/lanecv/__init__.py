@@ -22,9 +22,10 @@ import numpy as _np
 
 from . import _abi
 from ._abi import error
+from .glue import KalmanFilter   # host-side, as cv2.KalmanFilter is (`1000_Lane_Stabilizer.py:33`)
 
 __all__ = ["cvtColor", "resize", "GaussianBlur", "Canny", "fillPoly", "rectangle", "inRange", "bitwise_or", "bitwise_and",
-           "HoughLinesP", "addWeighted", "hough_accumulator", "error"]
+           "HoughLinesP", "addWeighted", "hough_accumulator", "KalmanFilter", "error"]
 
 COLOR_BGR2GRAY = 6
 COLOR_RGB2GRAY = 7

@@ -165,3 +165,75 @@ class PixelCurveTracker:
         left_fit, self.prev_left_fit = self._side(leftx, lefty, self.prev_left_fit)
         right_fit, self.prev_right_fit = self._side(rightx, righty, self.prev_right_fit)
         return self._curve(left_fit, ploty), self._curve(right_fit, ploty)
+
+
+class KalmanFilter:
+    """The linear Kalman filter of ``cv2.KalmanFilter(dynamParams, measureParams, controlParams)`` as the lane
+    stabiliser uses it (`1000_Lane_Stabilizer.py:33-63`): the same attribute names, float32 state, and the
+    predict / correct recurrences OpenCV documents --
+
+        predict:  x' = A x (+ B u),  P' = A P A^T + Q               (and x, P take these values until corrected)
+        correct:  K = P' H^T (H P' H^T + R)^-1,  x = x' + K (z - H x'),  P = P' - K H P'
+
+    Host-side glue on a 4-vector per lane: nothing here touches the GPU.  cv2 solves for K with an SVD in
+    float32; this class solves the same small system in float32 with numpy, so the last bits may differ."""
+
+    def __init__(self, dynamParams, measureParams, controlParams=0, dtype=np.float32):
+        dp, mp, cp = int(dynamParams), int(measureParams), int(controlParams)
+        if dp <= 0 or mp <= 0 or cp < 0:
+            raise ValueError("KalmanFilter: dynamParams and measureParams must be positive")
+        self._dtype = dtype
+        self.statePre = np.zeros((dp, 1), dtype)
+        self.statePost = np.zeros((dp, 1), dtype)
+        self.transitionMatrix = np.eye(dp, dtype=dtype)
+        self.processNoiseCov = np.eye(dp, dtype=dtype)
+        self.measurementMatrix = np.zeros((mp, dp), dtype)
+        self.measurementNoiseCov = np.eye(mp, dtype=dtype)
+        self.errorCovPre = np.zeros((dp, dp), dtype)
+        self.errorCovPost = np.zeros((dp, dp), dtype)
+        self.gain = np.zeros((dp, mp), dtype)
+        self.controlMatrix = np.zeros((dp, cp), dtype) if cp > 0 else None
+
+    def _m(self, a):
+        return np.asarray(a, dtype=self._dtype)
+
+    def predict(self, control=None):
+        A = self._m(self.transitionMatrix)
+        self.statePre = A @ self._m(self.statePost)
+        if control is not None and self.controlMatrix is not None:
+            self.statePre = self.statePre + self._m(self.controlMatrix) @ self._m(control).reshape(-1, 1)
+        self.errorCovPre = (A @ self._m(self.errorCovPost)) @ A.T + self._m(self.processNoiseCov)
+        # cv2 copies the prediction into the posterior, so that a frame without a measurement keeps predicting
+        self.statePost = self.statePre.copy()
+        self.errorCovPost = self.errorCovPre.copy()
+        return self.statePre
+
+    def correct(self, measurement):
+        H = self._m(self.measurementMatrix)
+        z = self._m(measurement).reshape(-1, 1)
+        HP = H @ self._m(self.errorCovPre)                       # H P'
+        S = HP @ H.T + self._m(self.measurementNoiseCov)         # innovation covariance
+        self.gain = np.linalg.solve(S, HP).T.astype(self._dtype)  # K = (S^-1 H P')^T, S and P' symmetric
+        self.statePost = self._m(self.statePre) + self.gain @ (z - H @ self._m(self.statePre))
+        self.errorCovPost = self._m(self.errorCovPre) - self.gain @ HP
+        return self.statePost
+
+
+class LaneKalmanFilter:
+    """`1000_Lane_Stabilizer.py:28-63`: a lane as (slope m, intercept b) with their per-frame changes, constant
+    velocity model, process noise 1e-4, measurement noise 0.1, unit initial covariance."""
+
+    def __init__(self):
+        kf = KalmanFilter(4, 2, 0)
+        kf.transitionMatrix = np.array([[1, 0, 1, 0], [0, 1, 0, 1], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+        kf.measurementMatrix = np.array([[1, 0, 0, 0], [0, 1, 0, 0]], np.float32)
+        kf.processNoiseCov = np.eye(4, dtype=np.float32) * 1e-4
+        kf.measurementNoiseCov = np.eye(2, dtype=np.float32) * 0.1
+        kf.errorCovPost = np.eye(4, dtype=np.float32)
+        self.kf = kf
+
+    def predict(self):
+        return self.kf.predict()
+
+    def correct(self, m, b):
+        return self.kf.correct(np.array([[np.float32(m)], [np.float32(b)]]))

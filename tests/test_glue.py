@@ -145,3 +145,44 @@ def test_pixel_curve_tracker_follows_the_f1_script():
                 assert got.dtype == np.int32 and got.shape == (1, h, 2)
                 assert (got[0, :, 0] == fx.astype(np.int32)).all() and (got[0, :, 1] == np.arange(h)).all()
     assert prev_l is not None and prev_r is not None
+
+
+def test_lane_kalman_stabiliser_follows_the_reference_recurrences():
+    """`1000_Lane_Stabilizer.py:69-96`: noisy (slope, intercept) measurements of a straight lane through the
+    stabiliser, against an independent float64 evaluation of the predict / correct recurrences (tolerance 1e-3
+    relative: the filter itself runs in float32, as cv2's does)."""
+    from lanecv.glue import KalmanFilter, LaneKalmanFilter
+    rng = np.random.default_rng(11)
+    frames = 100
+    ms = 0.5 + rng.normal(0, 0.1, frames)
+    bs = 100 + rng.normal(0, 5, frames)
+    lane = LaneKalmanFilter()
+    lane.kf.statePost = np.array([[ms[0]], [bs[0]], [0], [0]], dtype=np.float32)
+    A = np.array([[1, 0, 1, 0], [0, 1, 0, 1], [0, 0, 1, 0], [0, 0, 0, 1]], float)
+    Hm = np.array([[1, 0, 0, 0], [0, 1, 0, 0]], float)
+    Q, R, P = np.eye(4) * 1e-4, np.eye(2) * 0.1, np.eye(4)
+    x = np.array([[ms[0]], [bs[0]], [0], [0]], float)
+    out = []
+    for i in range(frames):
+        pre = lane.predict()
+        x, P = A @ x, A @ P @ A.T + Q
+        assert pre.dtype == np.float32 and pre.shape == (4, 1)
+        np.testing.assert_allclose(pre, x, rtol=1e-3, atol=1e-3)
+        est = lane.correct(ms[i], bs[i])
+        K = P @ Hm.T @ np.linalg.inv(Hm @ P @ Hm.T + R)
+        x = x + K @ (np.array([[ms[i]], [bs[i]]]) - Hm @ x)
+        P = P - K @ Hm @ P
+        assert est.dtype == np.float32 and est.shape == (4, 1)
+        np.testing.assert_allclose(est, x, rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(lane.kf.errorCovPost, P, rtol=2e-3, atol=1e-5)
+        out.append(est[:2, 0].copy())
+    out = np.array(out)
+    # what the script plots: the filtered track is far smoother than the measurements and settles on the lane
+    assert np.abs(np.diff(out[20:, 0])).mean() < 0.25 * np.abs(np.diff(ms[20:])).mean()
+    assert abs(out[-30:, 0].mean() - 0.5) < 0.05 and abs(out[-30:, 1].mean() - 100) < 2.5
+    # a frame without a measurement: predict alone carries the state on (cv2 copies the prediction to statePost)
+    before = lane.kf.statePost.copy()
+    lane.predict()
+    np.testing.assert_allclose(lane.kf.statePost, A.astype(np.float32) @ before, rtol=1e-6)
+    with pytest.raises(ValueError):
+        KalmanFilter(0, 2)
