@@ -16,6 +16,13 @@ import os
 import sys
 import time
 
+# The pipeline overlaps its stages on three or four HIP streams of equal priority, and the HIP runtime folds a process's
+# streams onto GPU_MAX_HW_QUEUES hardware queues (4 where this runs): together with torch's and RCCL's own streams two of
+# the pipeline's then share a queue and run one after the other (198 k instead of 327 k frames/s).  Eight queues keep
+# them apart; the variable is read when the HIP runtime starts, so it is set before torch is imported.
+if not os.environ.get("LANECV_KEEP_HW_QUEUES"):
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "image-processing_amd")):
     if p not in sys.path:
@@ -134,18 +141,42 @@ def main():
 
     import torch                       # first: liblanecv.so then binds to the HIP runtime torch loaded
     import torch.distributed as dist
+    # LANECV_BENCH_REHEARSE=1: every rank on GPU 0 and gloo between them -- runs the multi-rank code on a one-GPU
+    # box (sharding, barriers, max over ranks, the gather); its numbers mean nothing
+    rehearse = os.environ.get("LANECV_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # under torch.distributed.run the process group is set up even for a single rank: the one-GPU line then runs
+    # with RCCL's queues beside the pipeline's, like the ranks of a larger job
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_device = "cpu" if rehearse else "cuda"
+
+    if rehearse:
+        import faulthandler
+        faulthandler.dump_traceback_later(40, exit=True)      # a stuck rank says where, then ends the run
+
+    def note(msg):
+        if rehearse:
+            print("[rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
 
     from lanecv import _abi, shard
     from lanecv.pipeline import LanePipeline, Recipe
     rec = Recipe.north_star(W, H)
+    if os.environ.get("LANECV_BENCH_START_AT"):       # diagnostics: several benches on one GPU starting in step
+        while time.time() < float(os.environ["LANECV_BENCH_START_AT"]):
+            time.sleep(0.0005)
     pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=args.slots, seg_capacity=SEG_CAP, device=local_rank)
 
     dev_frames = torch.from_numpy(frames).cuda()                 # inputs resident in HBM
     torch.cuda.synchronize()
     ptr = dev_frames.data_ptr()
+    note("pipeline and frames ready")
 
     results = {}
     stage_names = {"front": _abi.STAGE_FRONT, "hyst": _abi.STAGE_HYST, "final": _abi.STAGE_FINAL,
@@ -170,21 +201,24 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     run(args.warmup)
+    note("warm-up done")
     stages = []
     barrier()
     t0 = time.perf_counter()
     run(args.steps, stages)
     # final result gather: per-frame segment counts and padded segment lists of the last batch to rank 0
     seg, cnt = results[(args.steps - 1) % args.slots]
-    gathered = shard.gather_segments(seg, cnt, dst=0, device="cuda" if world > 1 else None)
+    note("timed steps done")
+    gathered = shard.gather_segments(seg, cnt, dst=0, device=coll_device if use_dist else None)
+    note("gathered")
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if use_dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     fps = world * args.steps * batch / dt
@@ -268,7 +302,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     pipe.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -10,6 +10,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <thread>
 #include <algorithm>
 
 using namespace lanecv;
@@ -897,6 +899,11 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     return LC_OK;
 }
 
+int upload_stream(lc_pipe *pipe) {
+    if (!pipe->st_up) HIP_TRY(hipStreamCreateWithFlags(&pipe->st_up, hipStreamNonBlocking));
+    return LC_OK;
+}
+
 int get_slot(lc_pipe *pipe, int slot, Slot **out) {
     if (!pipe) return fail(LC_EINVAL, "null pipeline");
     if (slot < 0 || slot >= (int)pipe->slots.size()) return fail(LC_EINVAL, "slot %d out of range", slot);
@@ -982,14 +989,24 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     }
 
     {
-        hipError_t e = hipStreamCreateWithFlags(&pp->st_up, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&pp->st_edge, hipStreamNonBlocking);
+        // The post and HoughLinesP streams have the priority of the others.  At high priority their few workgroups
+        // were placed ahead of a front kernel's thousands a little sooner (327 k against 320 k frames/s at 1080p x
+        // 256), but both streams spend most of their time with a wait for another stream at the head of their queue,
+        // and whenever the process owned more hardware queues than this pipeline's (RCCL initialised, a second
+        // pipeline process on the GPU) the front kernel's queue was never served again: a hang at the first batch.
+        // LANECV_STREAM_PRIORITY=1 brings the high priority back for experiments.
+        const char *fp = getenv("LANECV_STREAM_PRIORITY");
+        const bool flat_priority = !(fp && fp[0] == '1');
+        // st_up is created by the first host submit: a pipeline that is only ever handed device frames keeps its
+        // stream count (and with it the number of hardware queues it wants) at three
+        hipError_t e = hipStreamCreateWithFlags(&pp->st_edge, hipStreamNonBlocking);
         const char *da = getenv("LANECV_LINES_DEFER");      // diagnostics: 0 / 1 / 2, see defer_after
         if (da && da[0] >= '0' && da[0] <= '2') pp->defer_after = da[0] - '0';
         const char *pr = getenv("LANECV_LINES_PRIORITY");   // diagnostics: 0 keeps HoughLinesP on the edge stream
         if (e == hipSuccess && p.want_segments && !(pr && pr[0] == '0')) {
             int lo_pri = 0, hi_pri = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+            if (flat_priority) hi_pri = lo_pri = 0;
             e = hipStreamCreateWithPriority(&pp->st_lines, hipStreamNonBlocking, hi_pri);
         }
         if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -1001,6 +1018,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         if (p.nslots > 1 && !(po && po[0] == '0')) {
             int lo_pri = 0, hi_pri = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+            if (flat_priority) hi_pri = lo_pri = 0;
             if (hipStreamCreateWithPriority(&pp->st_post, hipStreamNonBlocking, hi_pri) != hipSuccess) pp->st_post = pp->st_edge;
         }
         // with the post stream HoughLinesP starts as soon as its points are there (they are late enough: the short
@@ -1092,6 +1110,7 @@ int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nf
     s->input_bytes = (size_t)nframes * pipe->src_frame_bytes;
     uint8_t *own = pipe->resizes ? s->w.src_in.p : s->w.bgr.p;
     s->input = own;
+    if ((rc = upload_stream(pipe))) return rc;
     HIP_TRY(hipEventRecord(s->ev[EV_START], pipe->st_up));
     HIP_TRY(hipMemcpyAsync(own, host_bgr, s->input_bytes, hipMemcpyHostToDevice, pipe->st_up));
     return enqueue_all(pipe, *s, true);
@@ -1116,7 +1135,31 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
     if (pipe->deferred == slot) { enqueue_lines(pipe, *s, nullptr); pipe->deferred = -1; }
-    HIP_TRY(hipEventSynchronize(s->ev[s->end_ev]));
+    // LANECV_WAIT_TIMEOUT_S=<seconds>: poll instead of blocking, and give up with a report of which of the
+    // pipeline's events have fired (per slot, in the order of the EV_ enumeration) instead of hanging for ever
+    static const double wait_limit = getenv("LANECV_WAIT_TIMEOUT_S") ? atof(getenv("LANECV_WAIT_TIMEOUT_S")) : 0.0;
+    if (wait_limit > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipEventQuery(s->ev[s->end_ev]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIP_TRY(q);
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit) {
+                std::string rep;
+                for (size_t k = 0; k < pipe->slots.size(); k++) {
+                    Slot &o = pipe->slots[k];
+                    rep += " slot" + std::to_string(k) + (o.busy ? "*:" : ":");
+                    for (auto &ev : o.ev) rep += hipEventQuery(ev) == hipSuccess ? '1' : '0';
+                }
+                (void)hipGetLastError();
+                return fail(LC_EHIP, "wait: slot %d not finished after %.0f s; events fired (START UPLOADED FRONT HYST EDGE POINTS VOTE "
+                            "LINES END ESTART LSTART VSTART):%s", slot, wait_limit, rep.c_str());
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    } else {
+        HIP_TRY(hipEventSynchronize(s->ev[s->end_ev]));
+    }
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
     if (p.want_segments) {
@@ -1222,6 +1265,7 @@ int lc_pipe_upload(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "upload: bad frames argument");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
+    if ((rc = upload_stream(pipe))) return rc;
     HIP_TRY(hipMemcpyAsync(pipe->resizes ? s->w.src_in.p : s->w.bgr.p, host_bgr, (size_t)nframes * pipe->src_frame_bytes,
                            hipMemcpyHostToDevice, pipe->st_up));
     HIP_TRY(hipStreamSynchronize(pipe->st_up));
