@@ -780,11 +780,13 @@ struct lc_pipe {
     //   st_lines  HoughLinesP and the copy of the batch's results.  One workgroup per frame that wants most of a
     //             CU's LDS: high priority for the same reason.
     hipStream_t st_up = nullptr, st_edge = nullptr, st_post = nullptr, st_lines = nullptr;
-    // Second HoughLinesP stream, never created: kept as the place where more of them would go.  Batches smaller than
-    // the number of CUs would profit (HoughLinesP is one sequential workgroup per frame, a batch of 32 frames leaves
-    // 7/8 of the chip idle for 0.44 ms), but with three or more HoughLinesP streams on top of the other three the
-    // pipeline hung on this runtime (more streams than hardware queues, waits between streams that share one).
-    hipStream_t st_lines2 = nullptr;
+    // More HoughLinesP streams for small batches: the kernel is one sequential workgroup per frame that takes a CU
+    // for itself, so a batch of 32 frames leaves 7/8 of the chip to whatever may run beside it -- and on a single
+    // stream that is never another batch's HoughLinesP.  Batches take the streams in turn: CUs / max_batch of them,
+    // at most three and one fewer than there are slots (720p x 32: 71 k frames/s with one stream, 124 k with two
+    // of three slots, 146 k with three of six; four were slower again).  One stream when the batch fills the CUs (a
+    // second one gained nothing there); LANECV_LINES_STREAMS overrides the count.
+    std::vector<hipStream_t> st_lines_more;
     unsigned lines_turn = 0;
 
     // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs).  The HoughLinesP
@@ -836,7 +838,8 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
     const bool vote_fused = p.want_accumulator && p.want_segments;
     hipStream_t ls = es;   // the stream the batch finishes on
     if (p.want_segments) {
-        ls = (pp->st_lines2 && (pp->lines_turn++ & 1)) ? pp->st_lines2 : pp->st_lines;
+        const unsigned turn = pp->lines_turn++ % (unsigned)(1 + pp->st_lines_more.size());
+        ls = turn ? pp->st_lines_more[turn - 1] : pp->st_lines;
         if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[EV_POINTS], 0);
         if (ls != es && after) (void)hipStreamWaitEvent(ls, after, 0);
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
@@ -1009,6 +1012,19 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             if (flat_priority) hi_pri = lo_pri = 0;
             e = hipStreamCreateWithPriority(&pp->st_lines, hipStreamNonBlocking, hi_pri);
         }
+        if (e == hipSuccess && pp->st_lines) {
+            hipDeviceProp_t prop;
+            int want = 1;
+            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+                want = std::max(1, std::min(std::min(prop.multiProcessorCount / p.max_batch, p.nslots - 1), 3));
+            const char *ns = getenv("LANECV_LINES_STREAMS");
+            if (ns && ns[0] >= '1' && ns[0] <= '8') want = ns[0] - '0';
+            for (int k = 1; k < want && e == hipSuccess; k++) {
+                hipStream_t st = nullptr;
+                e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+                if (e == hipSuccess) pp->st_lines_more.push_back(st);
+            }
+        }
         if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
         if (!pp->st_lines) pp->st_lines = pp->st_edge;
         // the short kernels get a high-priority stream of their own when batches are pipelined: the next batch's
@@ -1087,7 +1103,7 @@ int lc_pipe_destroy(lc_pipe *pipe) {
     if (pipe->st_up) (void)hipStreamSynchronize(pipe->st_up);
     if (pipe->st_edge) (void)hipStreamSynchronize(pipe->st_edge);
     if (pipe->st_lines) (void)hipStreamSynchronize(pipe->st_lines);
-    if (pipe->st_lines2) { (void)hipStreamSynchronize(pipe->st_lines2); (void)hipStreamDestroy(pipe->st_lines2); }
+    for (hipStream_t st : pipe->st_lines_more) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (pipe->st_post && pipe->st_post != pipe->st_edge) { (void)hipStreamSynchronize(pipe->st_post); (void)hipStreamDestroy(pipe->st_post); }
     for (Slot &s : pipe->slots) {
         for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
