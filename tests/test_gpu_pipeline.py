@@ -70,23 +70,25 @@ def test_roi_matches_fillpoly_of_the_scripts(oracle):
         pipe.close()
 
 
-def test_slots_overlap_and_reuse(oracle):
-    """Three slots in flight at once, each reused: results must not depend on the slot or the order."""
+@pytest.mark.parametrize("nslots", [3, 5])
+def test_slots_overlap_and_reuse(oracle, nslots):
+    """All slots in flight at once, each reused: results must not depend on the slot or the order.  (Batches this
+    small take two HoughLinesP streams in turn with three slots, three with five.)"""
     from lanecv import synth
     from lanecv.pipeline import LanePipeline, Recipe
     w, h = 960, 540
     rec = Recipe.north_star(w, h)
-    pipe = LanePipeline(w, h, rec, max_batch=8, nslots=3)
-    pinned = [pipe.pinned_frames(8) for _ in range(3)]
+    pipe = LanePipeline(w, h, rec, max_batch=8, nslots=nslots)
+    pinned = [pipe.pinned_frames(8) for _ in range(nslots)]
     batches = []
-    for b in range(6):
+    for b in range(2 * nslots):
         fr = np.stack([synth.synth_road(w, h, seed=20 + b, t=t) for t in range(8 if b != 4 else 3)])
         batches.append(fr)
     results = {}
     inflight = []
     for b, fr in enumerate(batches):
-        slot = b % 3
-        if len(inflight) == 3:
+        slot = b % nslots
+        if len(inflight) == nslots:
             ob, oslot = inflight.pop(0)
             results[ob] = pipe.collect(oslot)
         pinned[slot][:len(fr)] = fr
