@@ -250,6 +250,7 @@ int ctx_work(lc_ctx *ctx, int w, int h) {
     if ((rc = ctx->work.init_points(w * h))) return rc;
     size_t n = (size_t)w * h;
     if ((rc = ctx->tmpA.alloc(n)) || (rc = ctx->tmpB.alloc(n)) || (rc = ctx->tmpC.alloc(n)) || (rc = ctx->tmpD.alloc(n))) return rc;
+    HIP_TRY(hipDeviceSynchronize());   // the clears above ran on the null stream, which ctx->stream does not wait for
     ctx->work_w = w; ctx->work_h = h;
     return LC_OK;
 }
@@ -1091,6 +1092,12 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             s.w.r_segcount = d; s.w.r_rounds = d + p.max_batch; s.w.r_status = d + 2 * (size_t)p.max_batch; s.w.r_seg = d + s.w.res_head;
             s.zero_copy = true;
         }
+    }
+    // the buffers were cleared with hipMemset, which may still be running on the null stream, and the pipeline's
+    // streams do not wait for that stream: nothing may be submitted before the clears have landed
+    {
+        const hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "pipeline set-up failed: %s", hipGetErrorString(e)); }
     }
     *out = pp;
     return LC_OK;
