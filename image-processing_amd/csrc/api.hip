@@ -768,18 +768,16 @@ struct lc_pipe {
     int src_w = 0, src_h = 0;
     size_t src_frame_bytes = 0;   // bytes of one submitted frame
     DevBuf<int> resize_tab;
-    // A pipeline owns four streams, whatever its number of slots; a slot is a set of buffers and events.
-    // (HIP maps streams onto a few hardware queues, so the count stays small; and the waits between streams run one
-    // way only -- st_up -> st_edge -> st_post -> st_lines: pairs of streams that waited on each other in turn have
-    // hung, as has a layout with a HoughLinesP stream per slot.)
-    //   st_up     host-to-device copies of submitted frames.
+    // A pipeline owns three or four streams of equal priority (more HoughLinesP streams for small batches, below),
+    // whatever its number of slots; a slot is a set of buffers and events.  HIP maps streams onto a few hardware
+    // queues, so the count stays small, and the waits between streams run one way only -- st_up -> st_edge ->
+    // st_post -> st_lines.
+    //   st_up     host-to-device copies of submitted frames (created by the first host submit).
     //   st_edge   the front kernels (and the leading resize) of all slots, in submission order, back to back.
     //             They fill the GPU by themselves, so two of them gain nothing from running side by side.
     //   st_post   the short latency-bound kernels behind a front kernel: hysteresis, finalize, compaction (and the
-    //             vote kernel of accumulator-only recipes).  High priority, so that their few workgroups are placed
-    //             ahead of the next front kernel's thousands; with a single slot it is st_edge itself.
-    //   st_lines  HoughLinesP and the copy of the batch's results.  One workgroup per frame that wants most of a
-    //             CU's LDS: high priority for the same reason.
+    //             vote kernel of accumulator-only recipes); with a single slot it is st_edge itself.
+    //   st_lines  HoughLinesP and the copy of the batch's results.
     hipStream_t st_up = nullptr, st_edge = nullptr, st_post = nullptr, st_lines = nullptr;
     // More HoughLinesP streams for small batches: the kernel is one sequential workgroup per frame that takes a CU
     // for itself, so a batch of 32 frames leaves 7/8 of the chip to whatever may run beside it -- and on a single
@@ -1028,7 +1026,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         }
         if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
         if (!pp->st_lines) pp->st_lines = pp->st_edge;
-        // the short kernels get a high-priority stream of their own when batches are pipelined: the next batch's
+        // the short kernels get a stream of their own when batches are pipelined: the next batch's
         // front kernel then starts at once and they run beside it (LANECV_POST_STREAM=0: keep them on st_edge)
         pp->st_post = pp->st_edge;
         const char *po = getenv("LANECV_POST_STREAM");
