@@ -763,6 +763,7 @@ struct lc_pipe {
     bool has_roi = false;
     bool has_gate = false;        // colour gate in front of the gray conversion
     GateDev gate{};
+    DevBuf<int> gate_tab;     // gate_tables_host: the HSV reciprocal tables and this gate's s/v intervals
     // cv2.resize in front of everything: submitted frames are src_w x src_h, the pipeline works on width x height
     bool resizes = false, resize_area2 = false;
     int src_w = 0, src_h = 0;
@@ -886,7 +887,7 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     }
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
-                 pp->has_gate ? &pp->gate : nullptr, pp->ctx->hsv_tab.p, w.gray.p, w.rowflags.p);
+                 pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
     hipStream_t ps = pp->st_post;
@@ -960,9 +961,13 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "resize table upload failed: %s", hipGetErrorString(e)); }
     }
     if (p.hsv_gate) {
-        if ((rc = ctx_hsv_tab(ctx))) { delete pp; return rc; }
         pp->has_gate = true;
         pp->gate = make_gate(p.hsv_bounds, 2);
+        std::vector<int> tab(768);
+        gate_tables_host(pp->gate, tab.data());
+        if ((rc = pp->gate_tab.alloc(tab.size()))) { delete pp; return rc; }
+        hipError_t e = hipMemcpy(pp->gate_tab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "gate table upload failed: %s", hipGetErrorString(e)); }
     }
 
     // ROI and car mask fold into one bit plane: keep = (roi == 255) && (car != 0)

@@ -39,12 +39,16 @@ struct AngleEntry {
 // Colour gate in front of the gray conversion: a pixel is kept when its 8-bit HSV value (hue range 180)
 // lies in either of two boxes.  A channel test is (x - lo) <= span on unsigned numbers; an empty range
 // has lo = 1000, span = 0.  Box 0 takes lo[0..2] / span[0..2] in H, S, V order, box 1 the rest.
-struct GateDev { int lo[6]; uint32_t span[6]; };
+// hue_any: bit k = box k accepts every hue; vmin: the smallest v at which a pixel can pass either box (256: none)
+struct GateDev { int lo[6]; uint32_t span[6]; int hue_any, vmin; };
 // bounds: lo0[3], hi0[3], lo1[3], hi1[3] as the inRange calls receive them (any integers);
 // nboxes = 1 leaves the second box empty
 GateDev make_gate(const int *bounds, int nboxes);
 // the two reciprocal tables of the HSV conversion, sdiv[256] then hdiv[256]
 void hsv_tables_host(int *tab512);
+// the streaming kernel's tables for one gate: the two reciprocal tables, then per v the diff intervals (bytes
+// dmin0, dmax0, dmin1, dmax1) inside which a pixel passes the saturation and value bounds of either box (gate_keep4)
+void gate_tables_host(GateDev &gate, int *tab768);   // also sets gate.vmin
 
 // cv::resize INTER_LINEAR tables for (sw, sh) -> (dw, dh): xofs[dw], ia[dw], yofs[dh], ib[dh] (weights packed
 // a0 | a1 << 16); returns true when the size pair is the exact 2x2 decimation OpenCV reroutes to its area code

@@ -28,37 +28,67 @@ __device__ __forceinline__ bool gate_pass(int h, int s, int v, const GateDev &gt
     return in0 || in1;
 }
 
-// p = B | G << 8 | R << 16 (bits 24-31 ignored): does the gate keep the pixel?
-// SHAPE 1 is the general form.  SHAPE 2 is the form of the lane script's two boxes, whatever their numbers
-// (gate_shape decides): box 0 = "any hue, saturation at most s0, value at least v0", box 1 = "hue inside
-// [a, b] with b < 150, saturation at least s1, value at least v1".  One-sided tests are a single compare, and
-// a hue interval below 150 needs no wrap of negative hues (they become 150..179, outside it; tested unwrapped
-// they are negative, which the unsigned compare rejects as well).
-template <int SHAPE>
+// p = B | G << 8 | R << 16 (bits 24-31 ignored): does the gate keep the pixel?  (the arithmetic form: full HSV
+// conversion and two box tests; the gated gray pre-pass of frames the streaming kernel cannot take uses it)
 __device__ __forceinline__ bool gate_keep(uint32_t p, const int *tab, const GateDev &gt) {
     const int b = (int)(p & 255u), g = (int)((p >> 8) & 255u), r = (int)((p >> 16) & 255u);
-    if constexpr (SHAPE == 2) {
-        const int v = max(b, max(g, r)), diff = v - min(b, min(g, r));
-        const int sd = tab[v], hd = tab[256 + diff];
-        const int s = (diff * sd + (1 << 11)) >> 12;
-        const int hh = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
-        const int h = (hh * hd + (1 << 11)) >> 12;                       // not wrapped
-        const bool in0 = s <= (int)gt.span[1] && v >= gt.lo[2];          // box 0: lo[1] is 0, so span[1] is the upper bound
-        const bool in1 = (uint32_t)(h - gt.lo[3]) <= gt.span[3] && s >= gt.lo[4] && v >= gt.lo[5];
-        return in0 || in1;
-    } else {
-        int h, s, v;
-        hsv_px(b, g, r, tab, h, s, v);
-        return gate_pass(h, s, v, gt);
-    }
+    int h, s, v;
+    hsv_px(b, g, r, tab, h, s, v);
+    return gate_pass(h, s, v, gt);
 }
 
-// 2 when the (normalised) gate has the lane script's form described above, else 1
-inline int gate_shape(const GateDev &gt) {
-    auto upper_open = [&](int i) { return gt.lo[i] <= 255 && gt.lo[i] + (long long)gt.span[i] >= 255; };   // no upper bound
-    const bool box0 = gt.lo[0] == 0 && gt.span[0] >= 179 && gt.lo[1] == 0 && gt.lo[2] <= 255 && upper_open(2);
-    const bool box1 = gt.lo[3] <= 255 && gt.lo[3] + (long long)gt.span[3] < 150 && upper_open(4) && upper_open(5);
-    return box0 && box1 ? 2 : 1;
+// Table form, four pixels at a time (the streaming kernel).  For a given v the saturation
+// s = (diff * sdiv[v] + 2^11) >> 12 does not decrease with diff, so "s and v inside box k" is "diff inside an
+// interval that depends on v": the host tabulates the interval of either box per v (gate_tables_host: tab[512 + v]
+// = dmin0 | dmax0 << 8 | dmin1 << 16 | dmax1 << 24; an empty interval is 255..0), and a pixel costs max, min, the
+// look-up and four compares.  The look-up is what bounds the kernel -- a per-lane load, 64 addresses per
+// instruction, which the texture addresser takes four a clock: 0.21 of the kernel's 0.73 ms, whatever the
+// arithmetic around it (the same table in registers behind ds_bpermute, one per quarter of the table, was
+// slower still: 0.89 ms).  Only lanes whose v reaches the smallest v with a non-empty interval (gt.vmin) load.
+// The hue is needed only by pixels that pass the s/v test of a box whose hue range is not the whole circle
+// (gt.hue_any, one bit per box) -- the yellow box of the lane script, a few pixels per frame -- and is computed
+// (as hsv_px does, with the wrap) only by wavefronts in which some lane needs it.
+__device__ __forceinline__ uint32_t gate_keep4(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, const int *tab, const GateDev &gt) {
+    const uint32_t p[4] = {p0, p1, p2, p3};
+    int v[4], diff[4];
+    bool s0[4], s1[4];
+    bool need = false;
+    const bool any0 = (gt.hue_any & 1) != 0, any1 = (gt.hue_any & 2) != 0;
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int b = (int)(p[k] & 255u), g = (int)((p[k] >> 8) & 255u), r = (int)((p[k] >> 16) & 255u);
+        v[k] = max(b, max(g, r));
+        diff[k] = v[k] - min(b, min(g, r));
+        e[k] = 0x00FF00FFu;                                 // both intervals empty
+        if (v[k] >= gt.vmin) e[k] = (uint32_t)tab[512 + v[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t d = (uint32_t)diff[k];
+        s0[k] = d >= (e[k] & 255u) && d <= ((e[k] >> 8) & 255u);
+        s1[k] = d >= ((e[k] >> 16) & 255u) && d <= (e[k] >> 24);
+        need |= (s0[k] && !any0) || (s1[k] && !any1);
+    }
+    uint32_t km = 0;
+    if (__ballot(need) != 0) {
+        asm volatile("" ::: "memory");     // stays a branch: the hue arithmetic must not be hoisted in front of it
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int b = (int)(p[k] & 255u), g = (int)((p[k] >> 8) & 255u), r = (int)((p[k] >> 16) & 255u);
+            const int hd = tab[256 + diff[k]];
+            const int hh = v[k] == r ? g - b : (v[k] == g ? b - r + 2 * diff[k] : r - g + 4 * diff[k]);
+            int h = (hh * hd + (1 << 11)) >> 12;
+            h += h < 0 ? 180 : 0;
+            const bool in0 = s0[k] && (any0 || (uint32_t)(h - gt.lo[0]) <= gt.span[0]);
+            const bool in1 = s1[k] && (any1 || (uint32_t)(h - gt.lo[3]) <= gt.span[3]);
+            km |= (in0 || in1) ? (0xFFu << (8 * k)) : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) km |= (s0[k] || s1[k]) ? (0xFFu << (8 * k)) : 0u;
+    }
+    return km;
 }
 
 }  // namespace lanecv

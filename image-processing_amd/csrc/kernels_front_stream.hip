@@ -110,7 +110,7 @@ struct FrontArgs {
     uint8_t *rowflags;       // [frame][strip][row]: the plane bytes last stored for that strip row were not all zero; or null
     int rows_per_unit, nseg, nstrips, nunits;
     int wg_chunk;            // logical workgroups per XCD (see the kernel)
-    const int *gate_tab;     // GATE only: the HSV reciprocal tables in device memory
+    const int *gate_tab;     // GATE only: the gate's tables in device memory (gate_tables_host)
     GateDev gate;
 };
 
@@ -121,14 +121,14 @@ constexpr int STRIP = 248;        // output columns of a wavefront
 template <int P> using Phase = std::integral_constant<int, P>;
 
 // GATE != 0: the colour gate of the HSV-gated script in front of the gray conversion -- a pixel outside both
-// HSV boxes counts as black, so its gray value is 0.  The two 256-entry reciprocal tables are read from global
-// memory (2 KiB, resident in every L1): the gray conversion of a row group sits between the wait for the group's
+// HSV boxes counts as black, so its gray value is 0 (gate_keep4 in gate.h).  Its tables are read from global
+// memory (3 KiB, resident in every L1): the gray conversion of a row group sits between the wait for the group's
 // pixels and the issue of the next group's loads, so the lookups of its 12 pixels go out together and cost one
 // cache round trip per group.  In LDS they would cost less per lookup, but beside a HoughLinesP workgroup a CU
 // has about 3 KiB of LDS left: one front-end workgroup per CU instead of five.
 // INTER: also store the gray (and blurred) images -- parity runs only; the variant without them keeps their
 // per-lane addresses out of the register budget.
-template <bool BLUR, int GATE, bool INTER>   // GATE: 0 none, 1 general, 2 the lane script's form (gate_keep)
+template <bool BLUR, int GATE, bool INTER>   // GATE: 0 none, 1 the colour gate
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const int *__restrict__ gtab = a.gate_tab;
     const int lane = threadIdx.x & 63;
@@ -215,11 +215,7 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         const uint32_t t2 = (dot4(p2, a.k_hi, 0) << 8) + dot4(p2, a.k_lo, 1u << 15);
         const uint32_t t3 = (dot4(p3, a.k_hi, 0) << 8) + dot4(p3, a.k_lo, 1u << 15);
         uint32_t G = __builtin_amdgcn_perm(t1, t0, 0x0c0c0602u) | __builtin_amdgcn_perm(t3, t2, 0x06020c0cu);
-        if constexpr (GATE != 0) {
-            const uint32_t km = (gate_keep<GATE>(p0, gtab, a.gate) ? 0x000000FFu : 0u) | (gate_keep<GATE>(p1, gtab, a.gate) ? 0x0000FF00u : 0u) |
-                                (gate_keep<GATE>(p2, gtab, a.gate) ? 0x00FF0000u : 0u) | (gate_keep<GATE>(p3, gtab, a.gate) ? 0xFF000000u : 0u);
-            G &= km;
-        }
+        if constexpr (GATE != 0) G &= gate_keep4(p0, p1, p2, p3, gtab, a.gate);
         if (INTER && a.gray_out && v >= y0 && v < y1) {
             if (inimg && emits) *reinterpret_cast<uint32_t *>(a.gray_out + (size_t)f * W * H + (size_t)v * W + px) = G;
         }
@@ -402,9 +398,7 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     const bool inter = gray_out || blur_out;
 #define LC_FS(B, G, I) hipLaunchKernelGGL((k_front_stream<B, G, I>), grid, block, 0, st, a)
 #define LC_FS2(B, G) do { if (inter) LC_FS(B, G, true); else LC_FS(B, G, false); } while (0)
-    const int shape = gate ? gate_shape(*gate) : 0;
-    if (shape == 2) { if (blur) LC_FS2(true, 2); else LC_FS2(false, 2); }
-    else if (shape == 1) { if (blur) LC_FS2(true, 1); else LC_FS2(false, 1); }
+    if (gate) { if (blur) LC_FS2(true, 1); else LC_FS2(false, 1); }
     else { if (blur) LC_FS2(true, 0); else LC_FS2(false, 0); }
 #undef LC_FS2
 #undef LC_FS

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_gate_gray(const uint8_t *__restrict__ s
     if (p0 >= npix) return;
     auto one = [&](uint32_t px) -> uint32_t {   // px = c0 | c1 << 8 | c2 << 16
         const uint32_t gy = ((px & 255) * k0 + ((px >> 8) & 255) * k1 + ((px >> 16) & 255) * k2 + (1 << 14)) >> 15;
-        return gate_keep<1>(px, tab, gate) ? gy : 0u;
+        return gate_keep(px, tab, gate) ? gy : 0u;
     };
     if (p0 + 4 <= npix) {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(src) + q * 3;
@@ -219,7 +219,32 @@ GateDev make_gate(const int *b, int nboxes) {
             g.lo[3 * box + c] = lo;
             g.span[3 * box + c] = (uint32_t)(hi - lo);
         }
+    g.hue_any = 0;
+    g.vmin = 0;
+    for (int box = 0; box < 2; box++)
+        if (g.lo[3 * box] == 0 && g.span[3 * box] >= 179u) g.hue_any |= 1 << box;
     return g;
+}
+
+void gate_tables_host(GateDev &g, int *tab) {
+    hsv_tables_host(tab);
+    g.vmin = 256;
+    for (int v = 0; v < 256; v++) {
+        int dmin[2], dmax[2];
+        for (int box = 0; box < 2; box++) {
+            dmin[box] = 255; dmax[box] = 0;
+            const long long vlo = g.lo[3 * box + 2], vhi = vlo + g.span[3 * box + 2];
+            if (v < vlo || v > vhi) continue;
+            const long long slo = g.lo[3 * box + 1], shi = slo + g.span[3 * box + 1];
+            int first = -1, last = -1;
+            for (int d = 0; d <= v; d++) {                       // diff never exceeds v
+                const int s = (d * tab[v] + (1 << 11)) >> 12;
+                if (s >= slo && s <= shi) { if (first < 0) first = d; last = d; }
+            }
+            if (first >= 0) { dmin[box] = first; dmax[box] = last; if (v < g.vmin) g.vmin = v; }
+        }
+        tab[512 + v] = (int)((uint32_t)dmin[0] | ((uint32_t)dmax[0] << 8) | ((uint32_t)dmin[1] << 16) | ((uint32_t)dmax[1] << 24));
+    }
 }
 
 bool resize_tables_host(int sw, int sh, int dw, int dh, int *xofs, int *ia, int *yofs, int *ib) {

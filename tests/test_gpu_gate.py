@@ -166,3 +166,25 @@ def test_fused_gate_forms(oracle, gi):
                 assert (gray[i] == oracle.gate_gray(f, gate)).all(), i
         pipe.close()
     assert (masked[True] == masked[False]).all()
+
+
+@pytest.mark.parametrize("gi", [0, 3, 4, 5])
+def test_fused_gate_every_colour(oracle, gi):
+    """Every one of the 2^24 colours (one 4096 x 4096 frame) through the streaming kernel's gate: the gated gray
+    must equal the oracle's for the script's boxes, a hue interval that reaches the wrapped hues, two-sided boxes
+    and a bounded V."""
+    from lanecv import _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w = h = 4096
+    c = np.arange(1 << 24, dtype=np.uint32)
+    frame = np.stack([c & 255, (c >> 8) & 255, c >> 16], axis=1).astype(np.uint8).reshape(1, h, w, 3)
+    rec = Recipe.hsv_gated(w, h)
+    rec.hsv_gate, rec.segments, rec.roi_vertices = GATES[gi], False, None
+    pipe = LanePipeline(w, h, rec, max_batch=1, nslots=1, keep_intermediates=True)
+    pipe.submit(0, frame)
+    pipe.wait(0)
+    gray = pipe.read(0, _abi.BUF_GRAY)[0]
+    pipe.close()
+    want = oracle.gate_gray(frame[0], GATES[gi])
+    bad = np.flatnonzero(gray.ravel() != want.ravel())
+    assert bad.size == 0, (bad.size, [tuple(frame[0].reshape(-1, 3)[i]) for i in bad[:5]])
