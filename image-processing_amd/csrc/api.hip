@@ -71,6 +71,9 @@ int hough_geo(int w, int h, double rho_d, double theta_d, HoughGeo &hg) {
     if (na > 1 && std::fabs(M_PI - (na - 1) * (double)theta) < (double)theta / 2) --na;
     const int nr = (int)lrintf((float)((w + h) * 2 + 1) / rho);
     if (na < 1 || nr < 1) return fail(LC_EINVAL, "HoughLinesP: degenerate accumulator %d x %d", na, nr);
+    // the vote kernels keep at least one angle's row of int32 bins in a CU's LDS
+    if (nr > 38000) return fail(LC_EUNSUPPORTED, "HoughLinesP: rho %g gives %d distance bins for a %d x %d image; at most 38000 are supported",
+                                rho_d, nr, w, h);
     hg.numangle = na;
     hg.numrho = nr;
     hg.tab.resize(na);

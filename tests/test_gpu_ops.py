@@ -253,6 +253,10 @@ def test_errors(cv2):
     with pytest.raises(cv2.error):
         cv2.HoughLinesP(g, 0, np.pi / 60, 10)
     with pytest.raises(cv2.error):
+        cv2.HoughLinesP(g, 1e-3, np.pi / 60, 10)                       # more distance bins than a row of LDS holds
+    with pytest.raises(cv2.error):
+        cv2.hough_accumulator(g, 1e-3, np.pi / 60)
+    with pytest.raises(cv2.error):
         cv2.bitwise_and(g, np.zeros((5, 5), np.uint8))
     c = np.zeros((4, 4, 3), np.uint8)
     with pytest.raises(cv2.error):
