@@ -202,3 +202,31 @@ def test_one_slot_many_batches(oracle, keep):
             got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
             assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (b, i)
     pipe.close()
+
+
+def test_dense_frames_take_the_general_path(oracle):
+    """Frames with more edge points than the LDS-resident HoughLinesP kernel takes (16383) are flagged by it and done
+    by the global-memory kernel, which also makes their full-vote accumulator; flagged and ordinary frames share
+    a batch.  The frame is noise above a flat lower part, sized so that the count lands between that limit and the
+    pipeline's point capacity (an eighth of the pixels)."""
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h = 640, 360
+    rec = Recipe(color_code=6, blur=False, canny=(100, 200), roi_vertices=None, accumulator=True,
+                 threshold=120, min_line_length=30, max_line_gap=5)
+    noise = synth.adversarial_frames(w, h)["noise"]
+    dense = None
+    for rows in range(60, h, 20):
+        f = np.full((h, w, 3), 90, np.uint8)
+        f[:rows] = noise[:rows]
+        n = np.count_nonzero(_oracle_frame(oracle, f, rec, None)["masked"])
+        if 17500 <= n <= 27000:
+            dense = f
+            break
+    assert dense is not None, "no noise height gives an edge count in the wanted range"
+    frames = np.stack([dense, synth.synth_road(w, h, seed=9, t=1), dense[:, ::-1].copy()])
+    pipe = LanePipeline(w, h, rec, max_batch=3, nslots=2, seg_capacity=8192)
+    for slot in (0, 1, 0):
+        _check_batch(oracle, pipe, frames, rec, slot=slot, check_inter=False)
+    assert pipe.read(0, _abi.BUF_NPOINTS).max() > 16383
+    pipe.close()
