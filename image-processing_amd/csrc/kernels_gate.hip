@@ -154,9 +154,11 @@ __global__ __launch_bounds__(256) void k_resize_linear3x4(const uint8_t *__restr
             const int sx = xofs[dx0 + p], a = ia[dx0 + p], a0 = (short)(a & 0xFFFF), a1 = a >> 16;
             // the right tap's weight is 0 wherever it would fall outside the row (sx = sw - 1), so reading the
             // six bytes at sx is enough: what lies behind the row's end is multiplied by zero
-            uint32_t l0, h0, l1, h1;
+            // the lower row's weight is 0 for every output row of an odd integer reduction (1080p -> 360p: the sample
+            // point falls on a source row): that row is then not read at all -- a third of the source instead of two
+            uint32_t l0, h0, l1 = 0, h1 = 0;
             taps6(src, row0 + (size_t)sx * 3, src_bytes, l0, h0);
-            taps6(src, row1 + (size_t)sx * 3, src_bytes, l1, h1);
+            if (wb1 != 0) taps6(src, row1 + (size_t)sx * 3, src_bytes, l1, h1);
             const uint32_t t0[6] = {l0 & 255, (l0 >> 8) & 255, (l0 >> 16) & 255, l0 >> 24, h0 & 255, (h0 >> 8) & 255};
             const uint32_t t1[6] = {l1 & 255, (l1 >> 8) & 255, (l1 >> 16) & 255, l1 >> 24, h1 & 255, (h1 >> 8) & 255};
 #pragma unroll
