@@ -278,7 +278,10 @@ void launch_resize_linear(const uint8_t *src, int sw, int sh, int cn, int nframe
                           const int *tabs, bool area2, hipStream_t st) {
     // tabs: xofs[dw], ia[dw], yofs[dh], ib[dh] back to back
     if (cn == 3 && dw % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
-        hipLaunchKernelGGL(k_resize_linear3x4, dim3((dw / 4 + 255) / 256, dh, nframes), dim3(256), 0, st, src, sw, sh,
+        // a row of dw / 4 threads: workgroups as wide as the row needs, in whole wavefronts (640 columns: 160 threads
+        // in a workgroup of 192, not 256)
+        const int tpr = dw / 4, bs = std::min(256, (tpr + 63) / 64 * 64);
+        hipLaunchKernelGGL(k_resize_linear3x4, dim3((tpr + bs - 1) / bs, dh, nframes), dim3(bs), 0, st, src, sw, sh,
                            (size_t)sw * sh * 3 * nframes, dst, dw, dh, tabs, tabs + dw, tabs + 2 * dw, tabs + 2 * dw + dh, area2 ? 1 : 0);
         return;
     }
