@@ -527,7 +527,8 @@ int lc_resize_linear(lc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src
     const bool area2 = resize_tables_host(sw, sh, dw, dh, tab.data(), tab.data() + dw, tab.data() + 2 * dw, tab.data() + 2 * dw + dh);
     HIP_TRY(hipMemcpyAsync(ctx->rs_tab.p, tab.data(), sizeof(int) * tn, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = up2d(ctx->rs_src.p, src, (size_t)sw * channels, sh, src_stride, ctx->stream))) return rc;
-    launch_resize_linear(ctx->rs_src.p, sw, sh, channels, 1, ctx->rs_dst.p, dw, dh, ctx->rs_tab.p, area2, ctx->stream);
+    const bool dec3 = !area2 && resize_is_decimate3(sw, sh, dw, dh, tab.data(), tab.data() + dw, tab.data() + 2 * dw, tab.data() + 2 * dw + dh);
+    launch_resize_linear(ctx->rs_src.p, sw, sh, channels, 1, ctx->rs_dst.p, dw, dh, ctx->rs_tab.p, area2, ctx->stream, dec3);
     return down2d(dst, dst_stride, ctx->rs_dst.p, (size_t)dw * channels, dh, ctx->stream);   // synchronises: tab may go
 }
 
@@ -768,7 +769,7 @@ struct lc_pipe {
     GateDev gate{};
     DevBuf<int> gate_tab;     // gate_tables_host: the HSV reciprocal tables and this gate's s/v intervals
     // cv2.resize in front of everything: submitted frames are src_w x src_h, the pipeline works on width x height
-    bool resizes = false, resize_area2 = false;
+    bool resizes = false, resize_area2 = false, resize_dec3 = false;
     int src_w = 0, src_h = 0;
     size_t src_frame_bytes = 0;   // bytes of one submitted frame
     DevBuf<int> resize_tab;
@@ -884,7 +885,7 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     }
     HIP_TRY(hipEventRecord(s.ev[EV_ESTART], es));
     if (pp->resizes) {
-        launch_resize_linear(s.input, pp->src_w, pp->src_h, 3, n, w.bgr.p, w.g.W, w.g.H, pp->resize_tab.p, pp->resize_area2, es);
+        launch_resize_linear(s.input, pp->src_w, pp->src_h, 3, n, w.bgr.p, w.g.W, w.g.H, pp->resize_tab.p, pp->resize_area2, es, pp->resize_dec3);
         s.input = w.bgr.p;
         s.input_bytes = (size_t)n * 3 * w.npix;
     }
@@ -959,6 +960,8 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         std::vector<int> tab(tn);
         pp->resize_area2 = resize_tables_host(pp->src_w, pp->src_h, p.width, p.height, tab.data(), tab.data() + p.width,
                                               tab.data() + 2 * p.width, tab.data() + 2 * p.width + p.height);
+        pp->resize_dec3 = !pp->resize_area2 && resize_is_decimate3(pp->src_w, pp->src_h, p.width, p.height, tab.data(), tab.data() + p.width,
+                                                                   tab.data() + 2 * p.width, tab.data() + 2 * p.width + p.height);
         if ((rc = pp->resize_tab.alloc(tn))) { delete pp; return rc; }
         hipError_t e = hipMemcpy(pp->resize_tab.p, tab.data(), sizeof(int) * tn, hipMemcpyHostToDevice);
         if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "resize table upload failed: %s", hipGetErrorString(e)); }

@@ -59,8 +59,11 @@ bool resize_tables_host(int sw, int sh, int dw, int dh, int *xofs, int *ia, int 
 void launch_add_weighted(const uint8_t *a, float alpha, const uint8_t *b, float beta, float gamma, uint8_t *dst, size_t n,
                          hipStream_t st);
 // dense frames [n][sh][sw][cn] -> [n][dh][dw][cn]; tabs = the four tables back to back in device memory
+// decimate3: resize_is_decimate3 said yes for these tables (3-channel frames with a width that is a multiple of 4 then
+// take a copy kernel)
 void launch_resize_linear(const uint8_t *src, int sw, int sh, int cn, int nframes, uint8_t *dst, int dw, int dh,
-                          const int *tabs, bool area2, hipStream_t st);
+                          const int *tabs, bool area2, hipStream_t st, bool decimate3 = false);
+bool resize_is_decimate3(int sw, int sh, int dw, int dh, const int *xofs, const int *ia, const int *yofs, const int *ib);
 // colour gate (kernels_gate.hip); tab = device copy of hsv_tables_host
 void launch_hsv(const uint8_t *src, size_t npix, int code, const int *tab, uint8_t *dst, hipStream_t st);
 void launch_in_range3(const uint8_t *src, size_t npix, GateDev box0, uint8_t *dst, hipStream_t st);

@@ -175,6 +175,26 @@ __global__ __launch_bounds__(256) void k_resize_linear3x4(const uint8_t *__restr
     out[2] = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
 }
 
+// Reduction by exactly three in both directions (1080p -> 640 x 360): every sample point of the bilinear formula
+// falls on a source pixel -- x = 3 dx + 1, y = 3 dy + 1 with weights (2048, 0) both ways, for which the fixed-point
+// expression returns the source byte itself -- so the result is that pixel's three bytes.  A thread makes four
+// output pixels from the 36 contiguous source bytes that hold them (two 16-byte loads and a 4-byte one at 4-byte
+// alignment; pixel p sits at bytes 9 p + 3 .. 9 p + 5).  The host takes this path only after checking the tables.
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void k_decimate3_3x4(const uint8_t *__restrict__ src, int sw, int sh, uint8_t *__restrict__ dst,
+                                                       int dw, int dh) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, f = blockIdx.z;
+    if (4 * t >= dw) return;
+    const uint8_t *base = src + ((size_t)f * sh + (size_t)(3 * dy + 1)) * (size_t)sw * 3 + (size_t)36 * t;
+    const u32x4a4 q0 = *reinterpret_cast<const u32x4a4 *>(base), q1 = *reinterpret_cast<const u32x4a4 *>(base + 16);
+    const uint32_t d[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, *reinterpret_cast<const uint32_t *>(base + 32)};
+    auto byte = [&](int i) -> uint32_t { return (d[i >> 2] >> (8 * (i & 3))) & 255u; };
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst + ((size_t)f * dh + dy) * (size_t)dw * 3 + (size_t)12 * t);
+    out[0] = byte(3) | (byte(4) << 8) | (byte(5) << 16) | (byte(12) << 24);
+    out[1] = byte(13) | (byte(14) << 8) | (byte(21) << 16) | (byte(22) << 24);
+    out[2] = byte(23) | (byte(30) << 8) | (byte(31) << 16) | (byte(32) << 24);
+}
+
 // cv::addWeighted on 8-bit data: saturate(cvRound(a * alpha + (b * beta + gamma))) in float, every product and
 // sum rounded on its own; four bytes per thread
 __device__ __forceinline__ uint32_t blend1(uint32_t a, uint32_t b, float fa, float fb, float fg) {
@@ -249,6 +269,15 @@ void gate_tables_host(GateDev &g, int *tab) {
     }
 }
 
+// true when the tables of a (sw, sh) -> (dw, dh) resize describe the plain reduction by three: every output pixel is
+// the source pixel (3 dx + 1, 3 dy + 1) with the whole weight
+bool resize_is_decimate3(int sw, int sh, int dw, int dh, const int *xofs, const int *ia, const int *yofs, const int *ib) {
+    if (sw != 3 * dw || sh != 3 * dh) return false;
+    for (int dx = 0; dx < dw; dx++) if (xofs[dx] != 3 * dx + 1 || ia[dx] != 2048) return false;
+    for (int dy = 0; dy < dh; dy++) if (yofs[dy] != 3 * dy + 1 || ib[dy] != 2048) return false;
+    return true;
+}
+
 bool resize_tables_host(int sw, int sh, int dw, int dh, int *xofs, int *ia, int *yofs, int *ib) {
     const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
     const int iscale_x = (int)std::lrint(scale_x), iscale_y = (int)std::lrint(scale_y);
@@ -275,9 +304,14 @@ bool resize_tables_host(int sw, int sh, int dw, int dh, int *xofs, int *ia, int 
 }
 
 void launch_resize_linear(const uint8_t *src, int sw, int sh, int cn, int nframes, uint8_t *dst, int dw, int dh,
-                          const int *tabs, bool area2, hipStream_t st) {
+                          const int *tabs, bool area2, hipStream_t st, bool decimate3) {
     // tabs: xofs[dw], ia[dw], yofs[dh], ib[dh] back to back
     if (cn == 3 && dw % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+        if (decimate3) {
+            const int tpr3 = dw / 4, bs3 = std::min(256, (tpr3 + 63) / 64 * 64);
+            hipLaunchKernelGGL(k_decimate3_3x4, dim3((tpr3 + bs3 - 1) / bs3, dh, nframes), dim3(bs3), 0, st, src, sw, sh, dst, dw, dh);
+            return;
+        }
         // a row of dw / 4 threads: workgroups as wide as the row needs, in whole wavefronts (640 columns: 160 threads
         // in a workgroup of 192, not 256)
         const int tpr = dw / 4, bs = std::min(256, (tpr + 63) / 64 * 64);
