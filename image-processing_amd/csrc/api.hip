@@ -12,6 +12,7 @@
 #include <vector>
 #include <chrono>
 #include <thread>
+#include <mutex>
 #include <algorithm>
 
 using namespace lanecv;
@@ -53,6 +54,14 @@ struct DevBuf {
         return LC_OK;
     }
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
     ~DevBuf() { release(); }
 };
 
@@ -236,6 +245,15 @@ int ctx_bind(lc_ctx *ctx) {
     return LC_OK;
 }
 
+// per-op calls: bind, and create the context's stream on first use -- a process that only runs pipelines never
+// owns it (HIP folds a process's streams onto a few hardware queues, and the pipeline's streams want them)
+int ctx_op(lc_ctx *ctx) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if (!ctx->stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    return LC_OK;
+}
+
 int check_image(const void *p, int w, int h, size_t stride, size_t min_stride, const char *what) {
     if (!p) return fail(LC_EINVAL, "%s: null image pointer", what);
     if (w <= 0 || h <= 0) return fail(LC_EINVAL, "%s: empty image %d x %d", what, w, h);
@@ -255,6 +273,17 @@ int ctx_work(lc_ctx *ctx, int w, int h) {
     if ((rc = ctx->tmpA.alloc(n)) || (rc = ctx->tmpB.alloc(n)) || (rc = ctx->tmpC.alloc(n)) || (rc = ctx->tmpD.alloc(n))) return rc;
     HIP_TRY(hipDeviceSynchronize());   // the clears above ran on the null stream, which ctx->stream does not wait for
     ctx->work_w = w; ctx->work_h = h;
+    return LC_OK;
+}
+
+// Canny's integer thresholds: swapped if out of order, floored
+int canny_thresholds(double t1, double t2, int &low, int &high) {
+    if (!(t1 == t1) || !(t2 == t2)) return fail(LC_EINVAL, "Canny: NaN threshold");
+    if (t1 > t2) std::swap(t1, t2);
+    t1 = std::max(-1e9, std::min(1e9, t1));
+    t2 = std::max(-1e9, std::min(1e9, t2));
+    low = (int)std::floor(t1);
+    high = (int)std::floor(t2);
     return LC_OK;
 }
 
@@ -278,6 +307,7 @@ int up2d(void *dst, const void *src, size_t row_bytes, int h, size_t stride, hip
     return LC_OK;
 }
 int down2d(void *dst, size_t stride, const void *src, size_t row_bytes, int h, hipStream_t st) {
+    HIP_TRY(hipGetLastError());   // a kernel launch of the call that failed (bad configuration, missing code object)
     HIP_TRY(hipMemcpy2DAsync(dst, stride, src, row_bytes, row_bytes, h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LC_OK;
@@ -379,8 +409,6 @@ int lc_create(int device, lc_ctx **out) {
     HIP_TRY(hipSetDevice(device));
     lc_ctx *ctx = new lc_ctx();
     ctx->device = device;
-    hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (se != hipSuccess) { delete ctx; return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
     *out = ctx;
     return LC_OK;
 }
@@ -406,7 +434,7 @@ int lc_host_free(void *p) {
 
 int lc_cvt_gray(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, int code, uint8_t *dst, size_t dst_stride) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if (code != LC_COLOR_BGR2GRAY && code != LC_COLOR_RGB2GRAY)
         return fail(LC_EUNSUPPORTED, "cvtColor: only COLOR_BGR2GRAY (6) and COLOR_RGB2GRAY (7) are supported, got %d", code);
     if ((rc = check_image(src, w, h, src_stride, 3 * (size_t)w, "cvtColor src"))) return rc;
@@ -419,7 +447,7 @@ int lc_cvt_gray(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride
 
 int lc_cvt_hsv(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, int code, uint8_t *dst, size_t dst_stride) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if (code != LC_COLOR_BGR2HSV && code != LC_COLOR_RGB2HSV)
         return fail(LC_EUNSUPPORTED, "cvtColor: only COLOR_BGR2HSV (40) and COLOR_RGB2HSV (41) are supported here, got %d", code);
     if ((rc = check_image(src, w, h, src_stride, 3 * (size_t)w, "cvtColor src"))) return rc;
@@ -433,7 +461,7 @@ int lc_cvt_hsv(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
 int lc_in_range3(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, const int *lowerb, const int *upperb,
                  uint8_t *dst, size_t dst_stride) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if (!lowerb || !upperb) return fail(LC_EINVAL, "inRange: null bounds");
     if ((rc = check_image(src, w, h, src_stride, 3 * (size_t)w, "inRange src"))) return rc;
     if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "inRange dst"))) return rc;
@@ -447,7 +475,7 @@ int lc_in_range3(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_strid
 int lc_or(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size_t b_stride, uint8_t *dst, size_t dst_stride,
           int w, int h) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(a, w, h, a_stride, (size_t)w, "bitwise_or src1"))) return rc;
     if ((rc = check_image(b, w, h, b_stride, (size_t)w, "bitwise_or src2"))) return rc;
     if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "bitwise_or dst"))) return rc;
@@ -461,7 +489,7 @@ int lc_or(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size
 int lc_and3_mask(lc_ctx *ctx, const uint8_t *src, size_t src_stride, const uint8_t *mask, size_t mask_stride, uint8_t *dst,
                  size_t dst_stride, int w, int h) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(src, w, h, src_stride, 3 * (size_t)w, "bitwise_and src"))) return rc;
     if ((rc = check_image(mask, w, h, mask_stride, (size_t)w, "bitwise_and mask"))) return rc;
     if ((rc = check_image(dst, w, h, dst_stride, 3 * (size_t)w, "bitwise_and dst"))) return rc;
@@ -475,7 +503,7 @@ int lc_and3_mask(lc_ctx *ctx, const uint8_t *src, size_t src_stride, const uint8
 int lc_add_weighted(lc_ctx *ctx, const uint8_t *a, size_t a_stride, double alpha, const uint8_t *b, size_t b_stride, double beta,
                     double gamma, uint8_t *dst, size_t dst_stride, int row_bytes, int h) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if (!a || !b || !dst) return fail(LC_EINVAL, "addWeighted: null image pointer");
     if (row_bytes <= 0 || h <= 0) return fail(LC_EINVAL, "addWeighted: empty image");
     if (a_stride < (size_t)row_bytes || b_stride < (size_t)row_bytes || dst_stride < (size_t)row_bytes)
@@ -493,7 +521,7 @@ int lc_add_weighted(lc_ctx *ctx, const uint8_t *a, size_t a_stride, double alpha
 
 int lc_lds_atomic_rate(lc_ctx *ctx, int run, int returning, double *gadds_per_s) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if (!gadds_per_s) return fail(LC_EINVAL, "lds_atomic_rate: null result pointer");
     if (run < 0 || run > 64) return fail(LC_EINVAL, "lds_atomic_rate: run length %d outside [0, 64]", run);
     hipDeviceProp_t prop;
@@ -514,7 +542,7 @@ int lc_lds_atomic_rate(lc_ctx *ctx, int run, int returning, double *gadds_per_s)
 int lc_resize_linear(lc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src_stride, int channels, uint8_t *dst, int dw, int dh,
                      size_t dst_stride) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if (channels != 1 && channels != 3) return fail(LC_EUNSUPPORTED, "resize: 1 or 3 channels are supported, got %d", channels);
     if ((rc = check_image(src, sw, sh, src_stride, (size_t)sw * channels, "resize src"))) return rc;
     if ((rc = check_image(dst, dw, dh, dst_stride, (size_t)dw * channels, "resize dst"))) return rc;
@@ -534,7 +562,7 @@ int lc_resize_linear(lc_ctx *ctx, const uint8_t *src, int sw, int sh, size_t src
 
 int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, uint8_t *dst, size_t dst_stride) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(src, w, h, src_stride, (size_t)w, "GaussianBlur src"))) return rc;
     if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "GaussianBlur dst"))) return rc;
     if ((rc = ctx_work(ctx, w, h))) return rc;
@@ -546,16 +574,11 @@ int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_strid
 int lc_canny(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, double t1, double t2, uint8_t *dst,
              size_t dst_stride) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(src, w, h, src_stride, (size_t)w, "Canny image"))) return rc;
     if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "Canny edges"))) return rc;
-    if (!(t1 == t1) || !(t2 == t2)) return fail(LC_EINVAL, "Canny: NaN threshold");
-    if (t1 > t2) std::swap(t1, t2);
-    if (t2 > 1e9) t2 = 1e9;
-    if (t1 > 1e9) t1 = 1e9;
-    if (t1 < -1e9) t1 = -1e9;
-    if (t2 < -1e9) t2 = -1e9;
-    const int low = (int)std::floor(t1), high = (int)std::floor(t2);
+    int low, high;
+    if ((rc = canny_thresholds(t1, t2, low, high))) return rc;
     if ((rc = ctx_work(ctx, w, h))) return rc;
     Work &wk = ctx->work;
     if ((rc = up2d(ctx->tmpA.p, src, w, h, src_stride, ctx->stream))) return rc;
@@ -569,7 +592,7 @@ int lc_canny(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, d
 int lc_and(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size_t b_stride, const uint8_t *mask,
            size_t mask_stride, uint8_t *dst, size_t dst_stride, int w, int h) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(a, w, h, a_stride, (size_t)w, "bitwise_and src1"))) return rc;
     if ((rc = check_image(b, w, h, b_stride, (size_t)w, "bitwise_and src2"))) return rc;
     if ((rc = check_image(dst, w, h, dst_stride, (size_t)w, "bitwise_and dst"))) return rc;
@@ -585,7 +608,7 @@ int lc_and(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, siz
 int lc_fill_poly(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride, const int32_t *pts, const int *npts, int ncontours,
                  int color) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(img, w, h, stride, (size_t)w, "fillPoly img"))) return rc;
     if (ncontours < 0 || (ncontours > 0 && (!pts || !npts))) return fail(LC_EINVAL, "fillPoly: bad contour arguments");
     color = color < 0 ? 0 : (color > 255 ? 255 : color);
@@ -657,7 +680,7 @@ int lc_fill_poly(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride, const i
 
 int lc_rectangle_filled(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride, int x1, int y1, int x2, int y2, int color) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(img, w, h, stride, (size_t)w, "rectangle img"))) return rc;
     color = color < 0 ? 0 : (color > 255 ? 255 : color);
     if (x1 > x2) std::swap(x1, x2);
@@ -684,7 +707,7 @@ int lc_hough_geometry(int w, int h, double rho, double theta, int *numangle, int
 int lc_hough_accum(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, double rho, double theta, int32_t *acc,
                    int acc_capacity, int *numangle, int *numrho) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(img, w, h, stride, (size_t)w, "hough image"))) return rc;
     if (!acc) return fail(LC_EINVAL, "null accumulator");
     if ((rc = ctx_work(ctx, w, h))) return rc;
@@ -697,6 +720,7 @@ int lc_hough_accum(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride,
     if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
     if ((rc = points_from_bytes(ctx, nullptr))) return rc;
     launch_vote(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.tab.p, na, nr, wk.acc_full.p, nullptr, ctx->stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(acc, wk.acc_full.p, sizeof(int32_t) * (size_t)na * nr, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return LC_OK;
@@ -705,7 +729,7 @@ int lc_hough_accum(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride,
 int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, double rho, double theta, int threshold,
                      double min_line_length, double max_line_gap, int32_t *out, int capacity, int *n) {
     int rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    if ((rc = ctx_op(ctx))) return rc;
     if ((rc = check_image(img, w, h, stride, (size_t)w, "HoughLinesP image"))) return rc;
     if (!n || capacity < 0 || (capacity > 0 && !out)) return fail(LC_EINVAL, "HoughLinesP: bad output arguments");
     *n = 0;
@@ -723,6 +747,7 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
                                        nullptr, ctx->stream);
     launch_ppht_general(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, wk.acc_ppht.p, threshold, line_length,
                         line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, fast ? wk.fallback.p : nullptr, ctx->stream);
+    HIP_TRY(hipGetLastError());
     int host[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(&host[0], wk.segcount.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&host[1], wk.status.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -896,7 +921,7 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
     hipStream_t ps = pp->st_post;
     if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, s.ev[EV_FRONT], 0));
-    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps);
+    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status);
     HIP_TRY(hipEventRecord(s.ev[EV_HYST], ps));
     if (pp->deferred >= 0) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_HYST]); pp->deferred = -1; }
     enqueue_back(pp, s);
@@ -1002,14 +1027,11 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     }
 
     {
-        // The post and HoughLinesP streams have the priority of the others.  At high priority their few workgroups
-        // were placed ahead of a front kernel's thousands a little sooner (327 k against 320 k frames/s at 1080p x
-        // 256), but both streams spend most of their time with a wait for another stream at the head of their queue,
-        // and whenever the process owned more hardware queues than this pipeline's (RCCL initialised, a second
+        // All streams have the same priority.  With the post and HoughLinesP streams at high priority their few
+        // workgroups were placed ahead of a front kernel's thousands a little sooner (327 k against 320 k frames/s at
+        // 1080p x 256), but both streams spend most of their time with a wait for another stream at the head of their
+        // queue, and whenever the process owned more hardware queues than this pipeline's (RCCL initialised, a second
         // pipeline process on the GPU) the front kernel's queue was never served again: a hang at the first batch.
-        // LANECV_STREAM_PRIORITY=1 brings the high priority back for experiments.
-        const char *fp = getenv("LANECV_STREAM_PRIORITY");
-        const bool flat_priority = !(fp && fp[0] == '1');
         // st_up is created by the first host submit: a pipeline that is only ever handed device frames keeps its
         // stream count (and with it the number of hardware queues it wants) at three
         hipError_t e = hipStreamCreateWithFlags(&pp->st_edge, hipStreamNonBlocking);
@@ -1017,10 +1039,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         if (da && da[0] >= '0' && da[0] <= '2') pp->defer_after = da[0] - '0';
         const char *pr = getenv("LANECV_LINES_PRIORITY");   // diagnostics: 0 keeps HoughLinesP on the edge stream
         if (e == hipSuccess && p.want_segments && !(pr && pr[0] == '0')) {
-            int lo_pri = 0, hi_pri = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
-            if (flat_priority) hi_pri = lo_pri = 0;
-            e = hipStreamCreateWithPriority(&pp->st_lines, hipStreamNonBlocking, hi_pri);
+            e = hipStreamCreateWithFlags(&pp->st_lines, hipStreamNonBlocking);
         }
         if (e == hipSuccess && pp->st_lines) {
             hipDeviceProp_t prop;
@@ -1028,7 +1047,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
                 want = std::max(1, std::min(std::min(prop.multiProcessorCount / p.max_batch, p.nslots - 1), 3));
             const char *ns = getenv("LANECV_LINES_STREAMS");
-            if (ns && ns[0] >= '1' && ns[0] <= '8') want = ns[0] - '0';
+            if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
             for (int k = 1; k < want && e == hipSuccess; k++) {
                 hipStream_t st = nullptr;
                 e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -1042,10 +1061,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         pp->st_post = pp->st_edge;
         const char *po = getenv("LANECV_POST_STREAM");
         if (p.nslots > 1 && !(po && po[0] == '0')) {
-            int lo_pri = 0, hi_pri = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
-            if (flat_priority) hi_pri = lo_pri = 0;
-            if (hipStreamCreateWithPriority(&pp->st_post, hipStreamNonBlocking, hi_pri) != hipSuccess) pp->st_post = pp->st_edge;
+            if (hipStreamCreateWithFlags(&pp->st_post, hipStreamNonBlocking) != hipSuccess) pp->st_post = pp->st_edge;
         }
         // with the post stream HoughLinesP starts as soon as its points are there (they are late enough: the short
         // kernels wait for room beside the next front kernel); deferring it behind the next front kernel on top
@@ -1167,16 +1183,20 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
     if (pipe->deferred == slot) { enqueue_lines(pipe, *s, nullptr); pipe->deferred = -1; }
-    // LANECV_WAIT_TIMEOUT_S=<seconds>: poll instead of blocking, and give up with a report of which of the
-    // pipeline's events have fired (per slot, in the order of the EV_ enumeration) instead of hanging for ever
-    static const double wait_limit = getenv("LANECV_WAIT_TIMEOUT_S") ? atof(getenv("LANECV_WAIT_TIMEOUT_S")) : 0.0;
+    // The wait polls the batch's last event and gives up after LANECV_WAIT_TIMEOUT_S seconds (default 120; 0 = block
+    // in hipEventSynchronize for ever) with a report of which of the pipeline's events have fired, per slot, in the
+    // order of the EV_ enumeration: a pipeline whose streams starve each other (more streams in the process than
+    // hardware queues, see lc_pipe_create) then fails loudly instead of hanging its caller.
+    static const double wait_limit = getenv("LANECV_WAIT_TIMEOUT_S") ? atof(getenv("LANECV_WAIT_TIMEOUT_S")) : 120.0;
     if (wait_limit > 0) {
         const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
+        for (unsigned spins = 0;; spins++) {
             const hipError_t q = hipEventQuery(s->ev[s->end_ev]);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) HIP_TRY(q);
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_limit) {
+            if ((spins & 63) != 63) continue;                     // the clock is read every 64th query
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > wait_limit) {
                 std::string rep;
                 for (size_t k = 0; k < pipe->slots.size(); k++) {
                     Slot &o = pipe->slots[k];
@@ -1187,16 +1207,21 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
                 return fail(LC_EHIP, "wait: slot %d not finished after %.0f s; events fired (START UPLOADED FRONT HYST EDGE POINTS VOTE "
                             "LINES END ESTART LSTART VSTART):%s", slot, wait_limit, rep.c_str());
             }
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (waited > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));   // a batch takes about a millisecond
         }
     } else {
         HIP_TRY(hipEventSynchronize(s->ev[s->end_ev]));
     }
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
+    if (p.want_segments || p.want_accumulator || p.want_points) {
+        if (s->h_status[0])
+            return fail(LC_ECAP, "a frame holds more edge points than the pipeline keeps per frame (%d): its point list, accumulator and "
+                        "segments are incomplete", s->w.nz_cap);
+        if (s->h_status[1])
+            return fail(LC_EINVAL, "HoughLinesP: a vote fell outside the accumulator (the angle table does not fit the image size)");
+    }
     if (p.want_segments) {
-        const int st = s->h_status[0] | (s->h_status[1] << 1);
-        if (st) return fail(LC_ECAP, "HoughLinesP: a frame holds more edge points than the pipeline's point capacity (status %d)", st);
         if (seg_count) memcpy(seg_count, s->h_segcount, sizeof(int) * s->nframes);
         if (seg_xyxy) memcpy(seg_xyxy, s->h_seg, sizeof(int32_t) * 4 * (size_t)s->nframes * s->w.seg_cap);
     }

@@ -98,8 +98,9 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 // kernel: those with weak pixels), then repeats over the tiles whose neighbours gained a strong border pixel
 // until a round flags none; rounds[f] receives the rounds frame f needed.  wake holds two arrays of
 // nframes * tiles flags (the second all zero on entry); both are all zero on exit.
+// status (may be null): two words this kernel zeroes; the kernels behind it on the stream raise them with plain stores
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
-                       hipStream_t st);
+                       hipStream_t st, int *status = nullptr);
 // roi_bits: one plane shared by all frames, or nullptr
 // prevbits (may be null): the masked bits of the previous call on the same masked_out / rowplane buffers, all
 // zero before the first (like those buffers); with it, and without edges_out, only what changed is written
@@ -109,13 +110,20 @@ void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t 
 void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t *dst, size_t n, hipStream_t st);
 void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowplane, int *rowcount, hipStream_t st);
 // points + Hough
-// edge points of each frame in scan order from its bit plane and per-row counts (which it clears); also
-// zeroes the two status words (may be null) the Hough kernels behind it raise with plain stores:
-// status[0] = a frame holds more points than the list's capacity, status[1] = a vote left the accumulator
+// edge points of each frame in scan order from its bit plane and per-row counts (which it clears).  status (may be
+// null) are two words an earlier kernel on the stream zeroed (launch_hysteresis) and this kernel and the Hough kernels
+// behind it raise with plain stores: status[0] = a frame holds more points than the list's capacity (raised here),
+// status[1] = a vote left the accumulator
 void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, uint32_t *nz, int nz_cap, int *npoints,
                    int *status, hipStream_t st);
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
                  int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st);
+// Opt-in to more than 64 KiB of dynamic LDS for a kernel.  The attribute holds for the current device only, so the
+// largest request is remembered per (call site, device); thread-safe.  Returns the HIP error of a failed opt-in.
+struct LdsOptIn {
+    size_t have[64] = {};
+    hipError_t ensure(const void *kernel, size_t bytes);
+};
 // LDS atomic-add rate probe (kernels_probe.hip): best of three launches; 0 on success
 int lds_atomic_probe(int run, bool returning, int blocks, int iters, int *sink, hipStream_t st, float *ms, double *adds);
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,

@@ -416,8 +416,9 @@ __device__ __forceinline__ void hysteresis_frame(const Geo &g, int f, uint64_t *
 __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__restrict__ planeS,
                                                            const uint64_t *__restrict__ planeW,
                                                            uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
-                                                           int *__restrict__ rounds_out) {
+                                                           int *__restrict__ rounds_out, int *__restrict__ status) {
     __shared__ int any;
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) status[0] = status[1] = 0;   // raised by the kernels behind this one
     hysteresis_frame(g, blockIdx.x, planeS, planeW, wakeA, wakeB, rounds_out, any);
 }
 
@@ -606,11 +607,11 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 }
 
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
-                       hipStream_t st) {
+                       hipStream_t st, int *status) {
     // wake holds two flag arrays of nframes * tiles words each.  The second is all zero on entry and both are on
     // exit (zeroed when allocated): the kernel clears every flag it consumes and stops when a round sets none.
     const int nt = g.TX * g.TY * nframes;
-    hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds);
+    hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds, status);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,

@@ -9,6 +9,7 @@
 #include "common.h"
 #include <climits>
 #include <algorithm>
+#include <mutex>
 
 namespace lanecv {
 namespace {
@@ -29,7 +30,6 @@ __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint6
                                                                int *__restrict__ npoints, int *__restrict__ status) {
     __shared__ int tot[POINTS_WAVES];
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (status && f == 0 && threadIdx.x == 0) status[0] = status[1] = 0;   // the Hough kernels behind this one raise them
     const int H = g.H, TX = g.TX;
     const int rpw = (H + POINTS_WAVES - 1) / POINTS_WAVES;
     const int r0 = min(H, wv * rpw), r1 = min(H, r0 + rpw);
@@ -48,7 +48,10 @@ __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint6
         off += i < wv ? t : 0;
         all += t;
     }
-    if (threadIdx.x == 0) npoints[f] = all;
+    if (threadIdx.x == 0) {
+        npoints[f] = all;
+        if (status && all > nz_cap) status[0] = 1;   // the list is cut short: whoever consumes it must not trust it
+    }
     if (s == 0) return;
     const uint64_t *wp = rowplane + ((size_t)f * H + r0) * TX;
     const int nwords = (r1 - r0) * TX;
@@ -1089,6 +1092,20 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
 
 }  // namespace
 
+hipError_t LdsOptIn::ensure(const void *kernel, size_t bytes) {
+    static std::mutex mu;
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    const int slot = dev & 63;
+    if (have[slot] >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have[slot] = bytes;
+    return e;
+}
+
 void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, uint32_t *nz, int nz_cap, int *npoints,
                    int *status, hipStream_t st) {
     hipLaunchKernelGGL(k_points, dim3(nframes), dim3(64 * POINTS_WAVES), 0, st, g, rowplane, rowcount, nz, nz_cap, npoints, status);
@@ -1114,11 +1131,8 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
     const int budget = 16 * 1024;
     const int apg = flags ? vote_apg(numangle, numrho, groups) : vote_apg(numangle, numrho, groups, budget);
     size_t lds = (size_t)apg * (numrho + 1) * 4;
-    static size_t attr_set = 0;
-    if (lds > 64 * 1024 && lds > attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = lds;
-    }
+    static LdsOptIn optin;
+    (void)optin.ensure(reinterpret_cast<const void *>(k_vote), lds);
     // the flagged launch (often no frame has work) is at most 8 blocks per frame: it must not queue thousands of
     // blocks that only look at a flag behind the waves of the kernels it shares the GPU with
     hipLaunchKernelGGL(k_vote, dim3(flags ? std::min(groups, 8) : groups, nframes), dim3(256), lds, st, nz, nz_cap, npoints, tab, numangle,
@@ -1138,11 +1152,8 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
     const int lds_bytes = 152 * 1024;
     const int lds_points = std::min(rng_len, LDS_BIAS - 1);
-    static bool fast_attr = false;
-    if (!fast_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_fast), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        fast_attr = true;
-    }
+    static LdsOptIn optin;
+    if (optin.ensure(reinterpret_cast<const void *>(k_ppht_fast), (size_t)lds_bytes) != hipSuccess) return false;
     hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(PPHT_THREADS), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                        numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
                        lds_bytes, acc_full);
@@ -1158,11 +1169,8 @@ void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int
     if (vote_acc) {
         apg = vote_apg(numangle, numrho, groups);
         lds = (size_t)apg * (numrho + 1) * 4;
-        static size_t attr_set = 0;
-        if (lds > 64 * 1024 && lds > attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ppht_general), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = lds;
-        }
+        static LdsOptIn optin;
+        (void)optin.ensure(reinterpret_cast<const void *>(k_ppht_general), lds);
     }
     hipLaunchKernelGGL(k_ppht_general, dim3(nframes), dim3(256), lds, st, g, nz, nz_cap, npoints, rowplane, tab, numangle, numrho,
                        acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, vote_acc, apg);

@@ -50,11 +50,12 @@ def _fit_line(xs, ys, max_y, min_y):
     return [int(poly(max_y)), max_y, int(poly(min_y)), min_y]
 
 
-def lane_lines(lines, height, min_abs_slope=0.5):
+def lane_lines(lines, height, min_abs_slope=0.5, min_y_frac=3 / 5):
     """The two lane lines of `..._2(images).py:116-153`: ``[[xl_start, max_y, xl_end, min_y], [xr_start, max_y,
-    xr_end, min_y]]`` with max_y = height and min_y = int(height * 3 / 5); a side without segments gives x = 0."""
+    xr_end, min_y]]`` with max_y = height and min_y = int(height * min_y_frac) -- 3 / 5 in most scripts, 0.65 in
+    `Simple Lane Detection with OpenCV_6(mp4).py:141`; a side without segments gives x = 0."""
     lx, ly, rx, ry = split_by_slope(lines, min_abs_slope)
-    min_y, max_y = int(height * (3 / 5)), int(height)
+    min_y, max_y = int(height * min_y_frac), int(height)
     left = _fit_line(lx, ly, max_y, min_y) or [0, max_y, 0, min_y]
     right = _fit_line(rx, ry, max_y, min_y) or [0, max_y, 0, min_y]
     return [left, right]
@@ -65,8 +66,10 @@ class LineSmoother:
     taken as is, later ones enter as ``int(prev * (1 - alpha) + curr * alpha)`` per integer; a frame without
     segments on a side leaves that side's line unchanged."""
 
-    def __init__(self, alpha=0.1, min_abs_slope=0.3):
-        self.alpha, self.min_abs_slope = alpha, min_abs_slope
+    def __init__(self, alpha=0.1, min_abs_slope=0.3, min_y_frac=3 / 5):
+        """min_y_frac: the lines are drawn up to row int(height * min_y_frac) -- 3 / 5 in `..._4(mp4).py`, 0.65 in
+        `Simple Lane Detection with OpenCV_6(mp4).py:141`."""
+        self.alpha, self.min_abs_slope, self.min_y_frac = alpha, min_abs_slope, min_y_frac
         self.left = None
         self.right = None
 
@@ -81,7 +84,7 @@ class LineSmoother:
     def update(self, lines, height):
         """Returns the list of lines to draw (0, 1 or 2 entries, left first)."""
         lx, ly, rx, ry = split_by_slope(lines, self.min_abs_slope)
-        min_y, max_y = int(height * (3 / 5)), int(height)
+        min_y, max_y = int(height * self.min_y_frac), int(height)
         self.left = self._blend(self.left, _fit_line(lx, ly, max_y, min_y))
         self.right = self._blend(self.right, _fit_line(rx, ry, max_y, min_y))
         return [ln for ln in (self.left, self.right) if ln is not None]

@@ -141,24 +141,33 @@ class LanePipeline:
         self._ctx = _abi.context(device)
         _abi.check(_abi.lib().lc_pipe_create(self._ctx, C.byref(p), C.byref(self._h)))
         self._n = [0] * self.nslots
+        self._keepalive = [None] * self.nslots     # host frames of the batch in flight, per slot (the copy is asynchronous)
+        self._pinned = []                          # page-locked blocks handed out by pinned_frames
         na, nr = C.c_int(), C.c_int()
         _abi.check(_abi.lib().lc_hough_geometry(self.w, self.h, float(recipe.rho), float(recipe.theta),
                                                 C.byref(na), C.byref(nr)))
         self.numangle, self.numrho = na.value, nr.value
 
     def close(self):
+        """Destroys the pipeline (which waits for its streams) and frees the page-locked blocks of `pinned_frames`:
+        arrays obtained from it must not be used afterwards."""
         h, self._h = getattr(self, "_h", None), None
         if h and _abi is not None and getattr(_abi, "_lib", None) is not None:
             _abi._lib.lc_pipe_destroy(h)
+            for p in getattr(self, "_pinned", []):
+                _abi._lib.lc_host_free(C.c_void_p(p))
+            self._pinned = []
+            self._keepalive = [None] * self.nslots
 
     __del__ = close
 
     def pinned_frames(self, n=None):
-        """A page-locked (n, h, w, 3) uint8 array for overlapped uploads; freed with the process."""
+        """A page-locked (n, h, w, 3) uint8 array for overlapped uploads; `close` frees it."""
         n = self.max_batch if n is None else n
         p = C.c_void_p()
         nbytes = n * self.sh * self.sw * 3
         _abi.check(_abi.lib().lc_host_alloc_pinned(nbytes, C.byref(p)))
+        self._pinned.append(p.value)
         buf = (C.c_uint8 * nbytes).from_address(p.value)
         return np.frombuffer(buf, np.uint8).reshape(n, self.sh, self.sw, 3)
 
@@ -172,7 +181,9 @@ class LanePipeline:
         frames = np.ascontiguousarray(frames)
         _abi.check(_abi.lib().lc_pipe_submit_host(self._h, slot, _abi.ptr(frames), len(frames)))
         self._n[slot] = len(frames)
-        self._keepalive = frames
+        # the copy runs asynchronously on the upload stream: the array (possibly a temporary made above) lives until
+        # the slot has been waited for
+        self._keepalive[slot] = frames
 
     def upload(self, slot, frames):
         """Copies frames into the slot's own HBM input buffer (synchronous) and returns its device pointer;
@@ -196,9 +207,15 @@ class LanePipeline:
         if self.recipe.segments:
             seg = np.empty((n, self.seg_capacity, 4), np.int32)
             cnt = np.empty(n, np.int32)
-            _abi.check(_abi.lib().lc_pipe_wait(self._h, slot, _abi.ptr(seg), _abi.ptr(cnt)))
+            try:
+                _abi.check(_abi.lib().lc_pipe_wait(self._h, slot, _abi.ptr(seg), _abi.ptr(cnt)))
+            finally:
+                self._keepalive[slot] = None
             return seg, cnt
-        _abi.check(_abi.lib().lc_pipe_wait(self._h, slot, None, None))
+        try:
+            _abi.check(_abi.lib().lc_pipe_wait(self._h, slot, None, None))
+        finally:
+            self._keepalive[slot] = None
         return None, None
 
     def collect(self, slot):

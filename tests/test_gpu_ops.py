@@ -280,3 +280,44 @@ def test_lds_atomic_rate_probe():
     assert own >= one * 0.99
     with pytest.raises(_abi.error):
         _abi.lds_atomic_rate(65, False)
+
+
+def test_size_switches_do_not_leak(cv2, oracle):
+    """The per-op calls keep one working set per image size and rebuild it when the size changes: alternating two
+    sizes must leave the GPU's free memory where it was."""
+    import hiprt
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    b = rng.integers(0, 256, (300, 400), dtype=np.uint8)
+    want_a, want_b = oracle.canny(a, 100, 200), oracle.canny(b, 100, 200)
+    for _ in range(3):
+        cv2.Canny(a, 100, 200)
+        cv2.Canny(b, 100, 200)
+    before = hiprt.free_bytes()
+    for _ in range(100):
+        assert np.array_equal(cv2.Canny(a, 100, 200), want_a)
+        assert np.array_equal(cv2.Canny(b, 100, 200), want_b)
+    after = hiprt.free_bytes()
+    assert before - after < (8 << 20), "free memory fell by %d bytes over 200 size switches" % (before - after)
+
+
+def test_point_capacity_overflow_is_reported_without_segments(oracle):
+    """A frame with more edge points than the pipeline keeps per frame must fail loudly even when only the
+    accumulator (no HoughLinesP) was asked for."""
+    import lanecv
+    from lanecv import synth
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h = 640, 360
+    rec = Recipe(color_code=6, blur=False, canny=(20, 40), roi_vertices=None, accumulator=True, segments=False)
+    pipe = LanePipeline(w, h, rec, max_batch=2, nslots=1)
+    noise = synth.adversarial_frames(w, h)["noise"]
+    assert np.count_nonzero(oracle.canny(oracle.cvt_gray(noise, 6), 20, 40)) > w * h // 8 + 1024
+    calm = synth.adversarial_frames(w, h)["ramps"]
+    assert np.count_nonzero(oracle.canny(oracle.cvt_gray(calm, 6), 20, 40)) < w * h // 8
+    pipe.submit(0, np.stack([calm, noise]))
+    with pytest.raises(lanecv.error) as e:
+        pipe.wait(0)
+    assert e.value.code == lanecv._abi.LC_ECAP
+    pipe.submit(0, np.stack([calm]))     # the slot stays usable, and the next batch starts with a clean status
+    pipe.wait(0)
+    pipe.close()
