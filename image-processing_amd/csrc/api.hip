@@ -225,9 +225,40 @@ struct Work {
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// Working memory of lc_canny_noalloc: a fixed device array instead of hipMalloc'ed buffers, so that the call
+// allocates nothing.  Every GPU the library runs on holds its own copy at its own address until the process ends.
+// `scratch` itself is only a host-side handle of the symbol: the device address comes from hipGetSymbolAddress
+// (scratch_address, per device) and is what host code passes to kernels and memsets.
+// Layout for a w x h image (TX = ceil(w / 64), TY = ceil(h / 64)):
+//   [planeS TX * h u64][planeW TX * h u64][wake 2 * TX * TY u32][rounds 1 i32]
+constexpr int NOALLOC_MAX_W = 4096, NOALLOC_MAX_H = 2304;          // covers 3840 x 2160
+constexpr size_t NOALLOC_PLANE_WORDS = (size_t)(NOALLOC_MAX_W / 64) * NOALLOC_MAX_H;
+constexpr size_t NOALLOC_WAKE_WORDS = 2 * (size_t)(NOALLOC_MAX_W / 64) * ((NOALLOC_MAX_H + 63) / 64);
+constexpr size_t NOALLOC_BYTES = 2 * NOALLOC_PLANE_WORDS * 8 + NOALLOC_WAKE_WORDS * 4 + 256;   // 2.4 MB
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+namespace {
+// device address of `scratch` on the current device, looked up once per device
+int scratch_address(int device, unsigned char **out) {
+    static std::mutex mu;
+    static unsigned char *addr[64] = {};
+    if (device < 0 || device >= 64) return fail(LC_EUNSUPPORTED, "device %d: at most 64 devices are supported", device);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!addr[device]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(LC_EHIP, "hipGetSymbolAddress returned a null address for the scratch array");
+        addr[device] = static_cast<unsigned char *>(p);
+    }
+    *out = addr[device];
+    return LC_OK;
+}
+}  // namespace
+
 struct lc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    unsigned char *scratch_dev = nullptr;   // this device's copy of `scratch` (set by lc_create)
     Work work;            // batch-1 working set of the per-op calls, keyed by (w, h)
     int work_w = 0, work_h = 0;
     DevBuf<uint8_t> tmpA, tmpB, tmpC, tmpD;
@@ -409,6 +440,7 @@ int lc_create(int device, lc_ctx **out) {
     HIP_TRY(hipSetDevice(device));
     lc_ctx *ctx = new lc_ctx();
     ctx->device = device;
+    if (int rc = scratch_address(device, &ctx->scratch_dev)) { delete ctx; return rc; }
     *out = ctx;
     return LC_OK;
 }
@@ -587,6 +619,37 @@ int lc_canny(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride, d
     launch_hysteresis(wk.g, 1, wk.planeS.p, wk.planeW.p, wk.wake.p, wk.rounds.p, ctx->stream);
     launch_finalize(wk.g, 1, wk.planeS.p, nullptr, ctx->tmpB.p, nullptr, nullptr, nullptr, ctx->stream);
     return down2d(dst, dst_stride, ctx->tmpB.p, w, h, ctx->stream);
+}
+
+int lc_canny_noalloc(lc_ctx *ctx, const void *dev_image, int w, int h, double t1, double t2, void *dev_edges, void *stream) {
+    int rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    if (!dev_image || !dev_edges) return fail(LC_EINVAL, "Canny: null device pointer");
+    if (w <= 0 || h <= 0) return fail(LC_EINVAL, "Canny: empty image %d x %d", w, h);
+    if (w > NOALLOC_MAX_W || h > NOALLOC_MAX_H)
+        return fail(LC_EUNSUPPORTED, "lc_canny_noalloc: %d x %d exceeds the fixed working memory (at most %d x %d); use lc_canny",
+                    w, h, NOALLOC_MAX_W, NOALLOC_MAX_H);
+    if (((uintptr_t)dev_edges & 15) != 0) return fail(LC_EINVAL, "lc_canny_noalloc: dev_edges must be 16-byte aligned");
+    int low, high;
+    if ((rc = canny_thresholds(t1, t2, low, high))) return rc;
+    if (!ctx->scratch_dev) return fail(LC_EHIP, "lc_canny_noalloc: the context has no scratch address");
+    const Geo g = make_geo(w, h);
+    const size_t plane_words = g.plane_words(), wake_words = 2 * (size_t)g.TX * g.TY;
+    unsigned char *base = ctx->scratch_dev;                                   // the device address, never `scratch` itself
+    uint64_t *planeS = reinterpret_cast<uint64_t *>(base);
+    uint64_t *planeW = planeS + plane_words;
+    uint32_t *wake = reinterpret_cast<uint32_t *>(planeW + plane_words);
+    int *rounds = reinterpret_cast<int *>(wake + wake_words);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the array keeps the previous call's contents: the wake flags must start at zero (a call that was cut short
+    // may have left some set); both planes are written whole by the front kernel before anything reads them
+    HIP_TRY(hipMemsetAsync(wake, 0, wake_words * sizeof(uint32_t), st));
+    launch_front(static_cast<const uint8_t *>(dev_image), (size_t)w * h, 0, LC_COLOR_BGR2GRAY, false, g, 1, low, high, planeS, planeW,
+                 wake, nullptr, nullptr, st);
+    launch_hysteresis(g, 1, planeS, planeW, wake, rounds, st);
+    launch_finalize(g, 1, planeS, nullptr, static_cast<uint8_t *>(dev_edges), nullptr, nullptr, nullptr, st);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
 }
 
 int lc_and(lc_ctx *ctx, const uint8_t *a, size_t a_stride, const uint8_t *b, size_t b_stride, const uint8_t *mask,

@@ -106,6 +106,20 @@ int lc_gaussian5(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_strid
 int lc_canny(lc_ctx *ctx, const uint8_t *src, int w, int h, size_t src_stride,
              double threshold1, double threshold2, uint8_t *dst, size_t dst_stride);
 
+/* No counterpart in the reference: cv2.Canny (same arithmetic and result as lc_canny) for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * The call makes no hipMalloc / hipFree and no allocating library call: its working memory (two class bit planes,
+ * the hysteresis work lists) is a fixed array of 2.4 MB inside the library's code object, one copy per GPU.
+ *   dev_image  DEVICE pointer, h rows of w gray bytes, dense
+ *   dev_edges  DEVICE pointer, h rows of w bytes (0 / 255), dense, 16-byte aligned
+ *   stream     a hipStream_t of the context's device (NULL: the device's null stream).  The kernels are enqueued
+ *              there and the call returns without waiting; the caller synchronises the stream.
+ * Limit: w <= 4096 and h <= 2304 (LC_EUNSUPPORTED beyond; lc_canny has no such limit).
+ * All calls on one GPU share the one array: calls that overlap in time on a GPU (different streams, threads or
+ * contexts) race -- keep them on one stream or order them with events. */
+int lc_canny_noalloc(lc_ctx *ctx, const void *dev_image, int w, int h, double threshold1, double threshold2,
+                     void *dev_edges, void *stream);
+
 /* cv2.fillPoly(img, pts, color) with LINE_8, shift 0, on an 8UC1 image, in place.
  * pts holds the (x, y) int32 pairs of all contours back to back, npts[i] vertices each.
  * Replaces: Simple Lane Detection with OpenCV_2(images).py:20,
