@@ -16,12 +16,10 @@ import os
 import sys
 import time
 
-# The pipeline overlaps its stages on three or four HIP streams of equal priority, and the HIP runtime folds a process's
-# streams onto GPU_MAX_HW_QUEUES hardware queues (4 where this runs): together with torch's and RCCL's own streams two of
-# the pipeline's then share a queue and run one after the other (198 k instead of 327 k frames/s).  Eight queues keep
-# them apart; the variable is read when the HIP runtime starts, so it is set before torch is imported.
-if not os.environ.get("LANECV_KEEP_HW_QUEUES"):
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# GPU_MAX_HW_QUEUES is left as the box sets it (4, HIP's own default): the pipeline picks streams that do not share a
+# hardware queue by itself (lc_pipe_create), and the bench line says how many could not ("streams_sharing_a_queue").
+# lc_pipe_wait gives up after this many seconds with a report of the events that fired instead of hanging a rank.
+os.environ.setdefault("LANECV_WAIT_TIMEOUT_S", "60")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "image-processing_amd")):
@@ -249,6 +247,8 @@ def main():
                                  "(HoughLinesP of the previous batch runs beside it); traffic = FETCH_SIZE (x2, gfx950) + "
                                  "WRITE_SIZE per launch from the committed rocprofv3 PMC passes of the same launch shape"},
             "stage_ms": {k: round(v, 4) for k, v in mean.items()},
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default 4)"),
+            "streams_sharing_a_queue": pipe.shared_queues(),
             "segments_frame0": int(cnt[0]), "gathered_ranks": len(gathered), "hyst_closure_rounds_max_total": list(pipe.hyst_rounds(0)),
         }
 

@@ -880,6 +880,7 @@ struct lc_pipe {
     // second one gained nothing there); LANECV_LINES_STREAMS overrides the count.
     std::vector<hipStream_t> st_lines_more;
     unsigned lines_turn = 0;
+    int shared_queues = 0;        // streams of this layout that found no hardware queue of their own (lc_pipe_create)
 
     // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs).  The HoughLinesP
     // step of a batch is therefore not queued when the batch is submitted but when the NEXT one is, behind that
@@ -994,8 +995,21 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
     return LC_OK;
 }
 
+// The copy stream, created by the first host submit (a pipeline fed device frames never owns it).  Copies run on the
+// DMA engines, but their packets still queue behind whatever shares the stream's hardware queue: picked like the rest.
 int upload_stream(lc_pipe *pipe) {
-    if (!pipe->st_up) HIP_TRY(hipStreamCreateWithFlags(&pipe->st_up, hipStreamNonBlocking));
+    if (pipe->st_up) return LC_OK;
+    for (Slot &s : pipe->slots)
+        if (s.busy) { HIP_TRY(hipStreamCreateWithFlags(&pipe->st_up, hipStreamNonBlocking)); return LC_OK; }   // no experiments beside work in flight
+    StreamPicker picker;
+    std::vector<hipStream_t> mine = {pipe->st_edge};
+    if (pipe->st_post != pipe->st_edge) mine.push_back(pipe->st_post);
+    if (pipe->st_lines != pipe->st_edge) mine.push_back(pipe->st_lines);
+    for (hipStream_t st : pipe->st_lines_more) mine.push_back(st);
+    bool own = true;
+    pipe->st_up = picker.pick(mine, &own);
+    if (!pipe->st_up) return fail(LC_EHIP, "hipStreamCreate failed for the upload stream");
+    if (!own) pipe->shared_queues++;
     return LC_OK;
 }
 
@@ -1097,34 +1111,55 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         // pipeline process on the GPU) the front kernel's queue was never served again: a hang at the first batch.
         // st_up is created by the first host submit: a pipeline that is only ever handed device frames keeps its
         // stream count (and with it the number of hardware queues it wants) at three
+        //
+        // HIP folds a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and kernels of
+        // streams that share one run one after the other -- which undoes the overlap this layout exists for (198 k
+        // instead of 327 k frames/s at 1080p x 256 when the post stream shared a queue).  Which streams share is
+        // HIP's business and depends on what else the process created, so every stream below is picked by
+        // experiment (StreamPicker): candidates are created until one runs side by side with the streams picked so
+        // far.  In the order of what the overlap is worth: HoughLinesP beside the front kernels, then the short
+        // kernels, then further HoughLinesP streams for small batches; a stream for which no queue of its own is
+        // left falls back to the stream it would otherwise have run beside (counted in `shared_queues`).
+        StreamPicker picker;
+        std::vector<hipStream_t> mine;
+        bool own = true;
         hipError_t e = hipStreamCreateWithFlags(&pp->st_edge, hipStreamNonBlocking);
+        if (e == hipSuccess) mine.push_back(pp->st_edge);
         const char *da = getenv("LANECV_LINES_DEFER");      // diagnostics: 0 / 1 / 2, see defer_after
         if (da && da[0] >= '0' && da[0] <= '2') pp->defer_after = da[0] - '0';
         const char *pr = getenv("LANECV_LINES_PRIORITY");   // diagnostics: 0 keeps HoughLinesP on the edge stream
         if (e == hipSuccess && p.want_segments && !(pr && pr[0] == '0')) {
-            e = hipStreamCreateWithFlags(&pp->st_lines, hipStreamNonBlocking);
-        }
-        if (e == hipSuccess && pp->st_lines) {
-            hipDeviceProp_t prop;
-            int want = 1;
-            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
-                want = std::max(1, std::min(std::min(prop.multiProcessorCount / p.max_batch, p.nslots - 1), 3));
-            const char *ns = getenv("LANECV_LINES_STREAMS");
-            if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
-            for (int k = 1; k < want && e == hipSuccess; k++) {
-                hipStream_t st = nullptr;
-                e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-                if (e == hipSuccess) pp->st_lines_more.push_back(st);
-            }
+            pp->st_lines = picker.pick(mine, &own);
+            if (!pp->st_lines) e = hipErrorOutOfMemory;
+            else { mine.push_back(pp->st_lines); pp->shared_queues += own ? 0 : 1; }
         }
         if (e != hipSuccess) { lc_pipe_destroy(pp); return fail(LC_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+        const bool own_lines = pp->st_lines != nullptr;
         if (!pp->st_lines) pp->st_lines = pp->st_edge;
         // the short kernels get a stream of their own when batches are pipelined: the next batch's
         // front kernel then starts at once and they run beside it (LANECV_POST_STREAM=0: keep them on st_edge)
         pp->st_post = pp->st_edge;
         const char *po = getenv("LANECV_POST_STREAM");
         if (p.nslots > 1 && !(po && po[0] == '0')) {
-            if (hipStreamCreateWithFlags(&pp->st_post, hipStreamNonBlocking) != hipSuccess) pp->st_post = pp->st_edge;
+            hipStream_t st = picker.pick(mine, &own);
+            if (st && own) { pp->st_post = st; mine.push_back(st); }
+            else {                                  // no queue of its own: behind the front kernels, as with one slot
+                if (st) picker.rejected.push_back(st);
+                pp->shared_queues++;
+            }
+        }
+        if (own_lines) {
+            hipDeviceProp_t prop;
+            int want = 1;
+            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+                want = std::max(1, std::min(std::min(prop.multiProcessorCount / p.max_batch, p.nslots - 1), 3));
+            const char *ns = getenv("LANECV_LINES_STREAMS");
+            if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
+            for (int k = 1; k < want; k++) {
+                hipStream_t st = picker.pick(mine, &own);
+                if (st && own) { pp->st_lines_more.push_back(st); mine.push_back(st); }
+                else { if (st) picker.rejected.push_back(st); pp->shared_queues++; break; }
+            }
         }
         // with the post stream HoughLinesP starts as soon as its points are there (they are late enough: the short
         // kernels wait for room beside the next front kernel); deferring it behind the next front kernel on top
@@ -1376,6 +1411,12 @@ int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_to
     for (int i = 0; i < s->nframes; i++) { mx = std::max(mx, s->h_rounds[i]); tot += s->h_rounds[i]; }
     if (rounds_max) *rounds_max = mx;
     if (rounds_total) *rounds_total = tot;
+    return LC_OK;
+}
+
+int lc_pipe_shared_queues(lc_pipe *pipe, int *count) {
+    if (!pipe || !count) return fail(LC_EINVAL, "null argument");
+    *count = pipe->shared_queues;
     return LC_OK;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 
 namespace lanecv {
 
@@ -123,6 +124,17 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
 struct LdsOptIn {
     size_t have[64] = {};
     hipError_t ensure(const void *kernel, size_t bytes);
+};
+// Streams that do not share a hardware queue (kernels_probe.hip).  pick() creates streams until it finds one whose
+// kernels run beside those of every stream in `others` (at most 12 tries, a few hundred microseconds each; the GPU
+// should be idle); failing that it returns the last stream tried and sets *own_queue to false.  Streams it tried and
+// dropped are destroyed with the picker.  LANECV_QUEUE_PROBE=0 switches the experiment off.
+struct StreamPicker {
+    int *flags_host = nullptr, *flags_dev = nullptr;
+    std::vector<hipStream_t> rejected;
+    bool side_by_side(hipStream_t a, hipStream_t b);
+    hipStream_t pick(const std::vector<hipStream_t> &others, bool *own_queue);
+    ~StreamPicker();
 };
 // LDS atomic-add rate probe (kernels_probe.hip): best of three launches; 0 on success
 int lds_atomic_probe(int run, bool returning, int blocks, int iters, int *sink, hipStream_t st, float *ms, double *adds);

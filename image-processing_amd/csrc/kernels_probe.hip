@@ -12,6 +12,8 @@
 // RET: the returning form (ds_add_rtn_u32, what HoughLinesP's vote uses to see the new count) instead of the
 // fire-and-forget form (ds_add_u32, what the full-vote accumulator uses).
 #include "common.h"
+#include <chrono>
+#include <cstdlib>
 
 namespace lanecv {
 namespace {
@@ -71,6 +73,81 @@ int lds_atomic_probe(int run, bool returning, int blocks, int iters, int *sink, 
     *ms = best;
     *adds = (double)blocks * 256.0 * PROBE_UNROLL * iters;
     return 0;
+}
+
+// ---- which streams share a hardware queue --------------------------------------------------------------------
+// HIP folds a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and kernels of two
+// streams that share one run one after the other.  StreamPicker finds out by experiment: a kernel on stream a spins
+// until the host releases it (bounded by a clock, so it always ends), a kernel on stream b raises a flag; if the
+// flag arrives while a is still spinning, the two streams sit on different queues.
+namespace {
+// flags (mapped pinned host memory): [0] release, [1] a started, [2] a finished, [3] b ran
+__global__ void k_queue_spin(volatile int *flags, long long max_ticks) {
+    flags[1] = 1;
+    const long long t0 = wall_clock64();                       // constant 100 MHz clock
+    while (flags[0] == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
+    flags[2] = 1;
+}
+__global__ void k_queue_flag(volatile int *flags) { flags[3] = 1; }
+
+double seconds_since(const std::chrono::steady_clock::time_point &t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+}  // namespace
+
+StreamPicker::~StreamPicker() {
+    for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+    if (flags_host) (void)hipHostFree(flags_host);
+}
+
+bool StreamPicker::side_by_side(hipStream_t a, hipStream_t b) {
+    if (!flags_host) {
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return true; }
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess || !dp) { (void)hipHostFree(hp); (void)hipGetLastError(); return true; }
+        flags_host = static_cast<int *>(hp);
+        flags_dev = static_cast<int *>(dp);
+    }
+    volatile int *f = flags_host;
+    f[0] = f[1] = f[2] = f[3] = 0;
+    hipLaunchKernelGGL(k_queue_spin, dim3(1), dim3(1), 0, a, flags_dev, 400000ll);     // at most 4 ms
+    auto t0 = std::chrono::steady_clock::now();
+    while (!f[1] && seconds_since(t0) < 3e-3) {}
+    bool beside = false;
+    if (f[1]) {
+        hipLaunchKernelGGL(k_queue_flag, dim3(1), dim3(1), 0, b, flags_dev);
+        t0 = std::chrono::steady_clock::now();
+        while (!f[3] && !f[2] && seconds_since(t0) < 1e-3) {}
+        beside = f[3] && !f[2];
+    }
+    f[0] = 1;
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    (void)hipGetLastError();
+    return beside;
+}
+
+hipStream_t StreamPicker::pick(const std::vector<hipStream_t> &others, bool *own_queue) {
+    static const char *off = getenv("LANECV_QUEUE_PROBE");     // 0: take the first stream HIP hands out, as it comes
+    const bool probe = !(off && off[0] == '0');
+    hipStream_t last = nullptr;
+    for (int tries = 0; tries < 12; tries++) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        bool ok = true;
+        if (probe)
+            for (hipStream_t o : others)
+                if (o && !side_by_side(o, st)) { ok = false; break; }
+        if (ok) {
+            if (last) rejected.push_back(last);
+            if (own_queue) *own_queue = true;
+            return st;
+        }
+        if (last) rejected.push_back(last);     // kept until the picker goes: destroyed now, HIP would hand its queue out again
+        last = st;
+    }
+    if (own_queue) *own_queue = false;
+    return last;                                 // shares a queue with one of `others` (or null: no stream at all)
 }
 
 }  // namespace lanecv

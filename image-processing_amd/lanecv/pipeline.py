@@ -262,6 +262,12 @@ class LanePipeline:
         _abi.check(_abi.lib().lc_pipe_hyst_rounds(self._h, slot, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def shared_queues(self):
+        """Streams of the pipeline that found no hardware queue of their own (0 = full overlap)."""
+        n = C.c_int()
+        _abi.check(_abi.lib().lc_pipe_shared_queues(self._h, C.byref(n)))
+        return n.value
+
     def stage_ms(self, slot, stage):
         ms = C.c_float()
         _abi.check(_abi.lib().lc_pipe_stage_ms(self._h, slot, stage, C.byref(ms)))

@@ -242,6 +242,11 @@ int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr);
 /* Hysteresis diagnostics of the slot's last batch: rounds until the fixed point (the first
  * included), maximum over the frames and total. */
 int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_total);
+/* Diagnostics with no counterpart in the reference: how many of the pipeline's streams found no hardware queue of
+ * their own when it was created (HIP folds a process's streams onto GPU_MAX_HW_QUEUES queues; the pipeline probes
+ * which ones share).  0 = every stage overlaps as designed; otherwise stages that were meant to run side by side
+ * were put on one stream. */
+int lc_pipe_shared_queues(lc_pipe *pipe, int *count);
 /* Synchronous copy of nframes host frames into the slot's own input buffer, nothing else:
  * a later lc_pipe_submit_device on that pointer then runs with the input resident in HBM. */
 int lc_pipe_upload(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes);

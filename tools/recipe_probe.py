@@ -4,8 +4,6 @@ hsv_gated; SRC_W SRC_H: size of the submitted frames when the pipeline resizes t
 import json
 import os
 
-if not os.environ.get("LANECV_KEEP_HW_QUEUES"):
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"    # before the HIP runtime starts: a hardware queue per pipeline stream
 import sys
 import time
 

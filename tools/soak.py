@@ -3,8 +3,6 @@ counts and (every 50th step) masked map and accumulator must equal the first res
 usage: python tools/soak.py [STEPS] [BATCH]"""
 import os
 
-if not os.environ.get("LANECV_KEEP_HW_QUEUES"):
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"    # before the HIP runtime starts: a hardware queue per pipeline stream
 import sys
 
 import numpy as np

@@ -4,8 +4,6 @@ usage: python tools/vote_probe.py [BATCH]"""
 import json
 import os
 
-if not os.environ.get("LANECV_KEEP_HW_QUEUES"):
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"    # before the HIP runtime starts: a hardware queue per pipeline stream
 import sys
 
 import numpy as np
