@@ -10,20 +10,31 @@
 //
 // Everything that depends only on the row is wave-uniform (the unit index goes through
 // v_readfirstlane), so row tests are scalar branches.  The row loop is unrolled three times with the
-// windows indexed by the phase, so no register is ever copied to age a window.  Sixteen-bit values
-// live as pairs: `e` = (pixel 0, pixel 2), `o` = (pixel 1, pixel 3) of the lane, and all the
-// per-pixel work from the vertical blur on is packed two-pixels-per-instruction math.
+// three-row windows indexed by the phase, so no register is ever copied to age a window.  Sixteen-bit
+// values live as pairs: `e` = (pixel 0, pixel 2), `o` = (pixel 1, pixel 3) of the lane.
+//
+// Instruction choice.  On gfx950 a SIMD issues the plain 32-bit v_add / v_sub / v_and / v_or / v_xor /
+// v_lshrrev / v_bitop3 at twice the rate of everything else this kernel could use (packed 16-bit math, v_dot4,
+// v_perm, v_alignbyte, DPP moves, three-operand integer forms: 4 cycles per wavefront instruction against 2,
+// measured by tools/valu_rate.hip), and the kernel is bound by vector issue.  So wherever the two halves of a
+// pair cannot disturb each other, a pair is handled by ONE 32-bit instruction: sums of non-negative halves that
+// stay below 2^16, and differences that are kept non-negative by a bias in each half.  Signed quantities
+// therefore travel with a bias (dx + 0x1000, dy + 0x0800, magnitude + 0x1800) that is taken off, or
+// compared against equally biased thresholds, where it matters.
 //
 // Arithmetic (bit-exact with OpenCV's 8U paths):
-//   gray   T = sum c_i * 2k_i + 2^15 by two v_dot4_u32_u8 (high / low coefficient bytes); gray = byte 2 of T
-//   blur   [1 4 6 4 1] horizontally by v_dot4 (+8), vertically as [1 2 1] applied twice in packed u16
-//          (the +8 becomes the +128 of the rounding), then >> 8
-//   Sobel  separable, packed i16: d = b(x+1) - b(x-1), s = b(x-1) + 2 b(x) + b(x+1),
-//          dx = d(y-1) + 2 d(y) + d(y+1), dy = s(y+1) - s(y-1); magnitude |dx| + |dy|
+//   gray   with doubled weights 2k = 256 k_hi + k_lo:  S = sum c_i k_hi_i + ((sum c_i k_lo_i + 2^15) >> 8) by two
+//          chained v_dot4_u32_u8; gray = byte 1 of S  (= (sum c_i k_i + 2^14) >> 15)
+//   blur   [1 4 6 4 1] horizontally by v_dot4 (+8); vertically as four running pair sums
+//          A(v) = H(v-1) + H(v), T(v) = A(v-1) + A(v), C(v) = T(v-1) + T(v), B(v) = C(v-1) + C(v) = 16 * ([1 4 6 4 1]
+//          over rows v-4 .. v) + 128, all below 2^16; blurred value = B >> 8
+//   Sobel  separable: d = b(x+1) - b(x-1) + 0x400, s = b(x-1) + 2 b(x) + b(x+1) per row;
+//          P(b) = d(b-1) + d(b), dx + 0x1000 = P(m) + P(m+1); dy + 0x800 = (s(m+1) | 0x800) - s(m-1);
+//          |dx| + 0x1000 = max(dx', 0x2000 - dx'), |dy| + 0x800 likewise, magnitude' = their sum (+ 0x1800)
 //   NMS    direction by the exact 16-bit form of OpenCV's 15-bit tan(22.5) test:
 //          q = floor(|dx| * 13573 / 2^15) = (|dx| * 53 + (|dx| * 5 >> 8)) >> 7   (13573 = 53 * 256 + 5)
 //          horizontal  <=>  |dy| < q + min(|dx|, 1);   vertical  <=>  |dy| > 2 |dx| + q
-//          comparisons are saturating subtractions, selections are v_bfi with 0 / 0xFFFF half masks
+//          "m > x" is bit 15 of (m | 0x8000) - 1 - x (one 32-bit subtraction per pair); selections are v_bitop3
 //   borders: gray reflects (101) for the blur, the Sobel input replicates, magnitudes outside the image are 0
 // Requires W % 4 == 0 (lanes are then wholly inside or wholly outside the image); other widths and
 // gray input take the tiled kernel in kernels_edge.hip.
@@ -54,8 +65,47 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot4(a, b, c, false);
 }
+// three-input bit operations (v_bitop3_b32, a double-rate instruction): T = truth table with a = 0xF0, b = 0xCC, c = 0xAA
+template <int T> __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, T);
+}
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {   // mask ? a : b, bitwise
-    return (mask & a) | (~mask & b);
+    return bitop3<0xCA>(mask, a, b);
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return bitop3<0xEA>(a, b, c); }   // (a & b) | c
+__device__ __forceinline__ uint32_t or_and(uint32_t a, uint32_t b, uint32_t c) { return bitop3<0xA8>(a, b, c); }   // (a | b) & c
+// 32-bit add / subtract on a pair of 16-bit halves that cannot carry or borrow into each other.  Inline assembly
+// so that the optimiser does not merge them back into three-operand or shifting forms, which issue at half the
+// rate.  (Their results never feed a DPP move or a lane read directly, and they never consume a v_dot4 result
+// directly: the compiler's hazard bookkeeping does not look inside assembly statements.)
+__device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub2(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_sub_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// the same with a wave-uniform operand held in a scalar register: k + v, k - v, v - k
+__device__ __forceinline__ uint32_t add2k(uint32_t v, uint32_t k) {
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t ksub2(uint32_t k, uint32_t v) {
+    uint32_t r;
+    asm("v_sub_u32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub2k(uint32_t v, uint32_t k) {
+    uint32_t r;
+    asm("v_subrev_u32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkmaxu(uint32_t a, uint32_t b) {
+    return R32(__builtin_elementwise_max(U2(a), U2(b)));
 }
 // packed u16 saturating a - b (0 where a <= b)
 __device__ __forceinline__ uint32_t satsub(uint32_t a, uint32_t b) {
@@ -149,33 +199,43 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const bool lb = px == -4;                      // the lane left of column 0 (strip 0 only)
     const int jW = (W - X0) >> 2;                  // the lane that starts at column W
     const bool rb = lane == jW;
-    const bool has_border = X0 < 0 || jW <= 63;    // wave-uniform
+    const bool has_border = __builtin_amdgcn_readfirstlane((int)(X0 < 0 || jW <= 63)) != 0;    // wave-uniform
     const uint8_t *fsrc = a.src + (size_t)f * 3 * W * H;
     // lanes outside the image load a valid pixel group instead of nothing: what they hold never reaches
     // an output (border lanes are rewritten below, magnitudes outside the image are forced to zero)
     const uint32_t lane_off = 3u * (uint32_t)min(max(px, 0), W - 4);
     constexpr int DB = BLUR ? 2 : 0;               // rows the blur delays the pipeline by
     constexpr uint32_t M8 = 0x00FF00FFu;
-    const uint32_t low2 = (uint32_t)min(max(a.low, 0), 32767) * 0x10001u;
-    const uint32_t high2 = (uint32_t)min(max(a.high, 0), 32767) * 0x10001u;
     // this lane's byte of the two bit planes (odd lanes 1..61 store: their nibble and the next lane's)
     const int bi = STRIP / 8 * s + ((lane - 1) >> 1);
     const bool stores = (lane & 1) && lane <= 61 && bi < 8 * TX;
     const bool emits = lane >= 1 && lane <= 62;
 
-    // three-row windows, slot = phase of the iteration that wrote it
-    Pair Hh[3] = {}, Tt[3] = {};                   // horizontal blur sums (+8), first vertical [1 2 1] pass
-    Pair Dw[3] = {}, Sw[3] = {};                   // Sobel partial sums of the Sobel input rows
-    Pair Mw[3] = {};                               // magnitudes
-    Pair DXw[3] = {}, DYw[3] = {};                 // gradients
+    // thresholds: no magnitude exceeds 2040, so anything above behaves like 2041
+    const uint32_t low2 = (uint32_t)min(max(a.low, 0), 2041) * 0x10001u;
+    const uint32_t high2 = (uint32_t)min(max(a.high, 0), 2041) * 0x10001u;
+    // m + trigK has bit 15 set  <=>  m > low.  Only the emitting lanes decide whether a row needs the NMS block: the
+    // halo lanes' magnitudes come from a truncated neighbourhood and would trigger every row, so they add nothing.
+    const uint32_t trigK = emits ? 0x7FFF7FFFu - low2 : 0u;
+    // running pair sums of the vertical blur (previous row's values)
+    Pair Hp = {}, Ap = {}, Tp = {}, Cp = {};
+    // Sobel: previous row's d and pair sum P; three-row windows (slot = phase of the iteration that wrote it) of s
+    // and of the magnitudes; gradients of the current and the previous magnitude row
+    Pair Dp = {}, Pp = {};
+    Pair Sw[3] = {};
+    Pair Mw[3] = {};
+    Pair DXw[3] = {}, DYw[3] = {};
 
     uint32_t L[3][3] = {};                         // source rows of a group: consumed by the gray conversion at the
                                                    // top of the group, then reloaded with the next group's rows
     uint32_t pend[3] = {};                         // plane bytes of the group just finished (strong | weak << 8)
+    // A row is one 12-byte buffer load per lane: the frame as the buffer, the lane's column offset in a vector
+    // register that never changes, the row's offset in a scalar register -- no vector arithmetic per load.
+    const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fsrc), 0, 3 * W * H, 0x00020000);
     auto load_row = [&](int v, uint32_t (&r)[3]) {
         const int rs = BLUR ? reflect101s(v, H) : (v < 0 ? 0 : (v >= H ? H - 1 : v));
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(fsrc + (size_t)rs * W * 3 + lane_off);
-        r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
+        const auto q = __builtin_amdgcn_raw_buffer_load_b96(frame, lane_off, (uint32_t)rs * (uint32_t)(3 * W), 0);
+        r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
     };
     // Dirty tracking of the plane rows (rowflags != null; the planes then start all zero and only this kernel and the
     // hysteresis kernel, which adds strong bits where weak ones are, write them): a strip row whose bytes were zero
@@ -206,28 +266,42 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
 
     const int vend = y1 - 1 + DB + 2;
 
-    // ---- gray: 4 pixels (12 bytes) of source row v -> one packed dword ------------------------------
-    auto gray_row = [&](const uint32_t (&r)[3], const int v) -> uint32_t {
+    // ---- gray: 4 pixels (12 bytes) of source row v -> the gray bytes packed in one dword (BLUR, GATE, INTER) or
+    // ---- directly as the pairs e = (px0, px2), o = (px1, px3) ------------------------------------------------
+    constexpr bool PACKED_GRAY = BLUR || GATE != 0 || INTER;
+    auto gray_row = [&](const uint32_t (&r)[3], const int v) -> Pair {
         const uint32_t w0 = r[0], w1 = r[1], w2 = r[2];
-        const uint32_t p0 = w0, p1 = alignbyte(w1, w0, 3), p2 = alignbyte(w2, w1, 2), p3 = w2 >> 8;
-        const uint32_t t0 = (dot4(p0, a.k_hi, 0) << 8) + dot4(p0, a.k_lo, 1u << 15);
-        const uint32_t t1 = (dot4(p1, a.k_hi, 0) << 8) + dot4(p1, a.k_lo, 1u << 15);
-        const uint32_t t2 = (dot4(p2, a.k_hi, 0) << 8) + dot4(p2, a.k_lo, 1u << 15);
-        const uint32_t t3 = (dot4(p3, a.k_hi, 0) << 8) + dot4(p3, a.k_lo, 1u << 15);
-        uint32_t G = __builtin_amdgcn_perm(t1, t0, 0x0c0c0602u) | __builtin_amdgcn_perm(t3, t2, 0x06020c0cu);
-        if constexpr (GATE != 0) G &= gate_keep4(p0, p1, p2, p3, gtab, a.gate);
-        if (INTER && a.gray_out && v >= y0 && v < y1) {
-            if (inimg && emits) *reinterpret_cast<uint32_t *>(a.gray_out + (size_t)f * W * H + (size_t)v * W + px) = G;
+        // pixel 3 sits in bytes 1..3 of w2: it takes the weights moved up a byte instead of a shifted copy
+        const uint32_t p0 = w0, p1 = alignbyte(w1, w0, 3), p2 = alignbyte(w2, w1, 2);
+        // the four low-byte sums first, then their shifts, then the four high-byte sums: a v_dot4 result is not
+        // ready for a different kind of instruction at once
+        const uint32_t l0 = dot4(p0, a.k_lo, 1u << 15), l1 = dot4(p1, a.k_lo, 1u << 15);
+        const uint32_t l2 = dot4(p2, a.k_lo, 1u << 15), l3 = dot4(w2, a.k_lo << 8, 1u << 15);
+        const uint32_t t0 = dot4(p0, a.k_hi, l0 >> 8), t1 = dot4(p1, a.k_hi, l1 >> 8);
+        const uint32_t t2 = dot4(p2, a.k_hi, l2 >> 8), t3 = dot4(w2, a.k_hi << 8, l3 >> 8);
+        const uint32_t p3 = GATE != 0 ? w2 >> 8 : 0u;
+        Pair g;
+        if constexpr (PACKED_GRAY) {
+            uint32_t G = __builtin_amdgcn_perm(t1, t0, 0x0c0c0501u) | __builtin_amdgcn_perm(t3, t2, 0x05010c0cu);
+            if constexpr (GATE != 0) G &= gate_keep4(p0, p1, p2, p3, gtab, a.gate);
+            if (INTER && a.gray_out && v >= y0 && v < y1) {
+                if (inimg && emits) *reinterpret_cast<uint32_t *>(a.gray_out + (size_t)f * W * H + (size_t)v * W + px) = G;
+            }
+            g.e = G; g.o = 0;
+        } else {
+            g.e = __builtin_amdgcn_perm(t2, t0, 0x0c050c01u);
+            g.o = __builtin_amdgcn_perm(t3, t1, 0x0c050c01u);
         }
-        return G;
+        return g;
     };
 
-    auto step = [&](auto phase, const int v, uint32_t G) {
+    auto step = [&](auto phase, const int v, const Pair gray) {
         constexpr int P = decltype(phase)::value, PREV = (P + 2) % 3, OLD = (P + 1) % 3;
 
-        // ---- Sobel input row (blurred row v-2, or the gray row itself) as pairs -----------------
+        // ---- Sobel input row b = v - DB (blurred row v-2, or the gray row itself) as pairs -------------------
         uint32_t be, bo;
         if constexpr (BLUR) {
+            uint32_t G = gray.e;
             if (has_border) {   // reflect 101: columns -1,-2 mirror 1,2; columns W,W+1 mirror W-2,W-3
                 const uint32_t GR0 = from_right(G), GL0 = from_left(G);
                 if (lb) G = (GR0 & 0x00FF0000u) | ((GR0 << 16) & 0xFF000000u);
@@ -239,82 +313,95 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             const uint32_t h1 = dot4(q1, 0x04060401u, dot4(G, 0x01000000u, 8));
             const uint32_t h2 = dot4(G, 0x04060401u, dot4(GR, 0x00000001u, 8));
             const uint32_t h3 = dot4(q3, 0x04060401u, dot4(GR, 0x00000100u, 8));
-            Hh[P].e = h0 | (h2 << 16);
-            Hh[P].o = h1 | (h3 << 16);
-            // t(v-1) = h(v-2) + 2 h(v-1) + h(v);  16 (b(v-2) + 8) = t(v-3) + 2 t(v-2) + t(v-1)
-            Tt[P].e = pkmad2(Hh[PREV].e, pkadd(Hh[OLD].e, Hh[P].e));
-            Tt[P].o = pkmad2(Hh[PREV].o, pkadd(Hh[OLD].o, Hh[P].o));
-            be = R32(U2(pkmad2(Tt[PREV].e, pkadd(Tt[OLD].e, Tt[P].e))) >> (unsigned short)8);
-            bo = R32(U2(pkmad2(Tt[PREV].o, pkadd(Tt[OLD].o, Tt[P].o))) >> (unsigned short)8);
+            Pair Hc, Ac, Tc, Cc;
+            Hc.e = h0 | (h2 << 16);
+            Hc.o = h1 | (h3 << 16);
+            // running pair sums (see the head of the file); every sum stays below 2^16 in each half
+            Ac.e = add2(Hp.e, Hc.e); Ac.o = add2(Hp.o, Hc.o);
+            Tc.e = add2(Ap.e, Ac.e); Tc.o = add2(Ap.o, Ac.o);
+            Cc.e = add2(Tp.e, Tc.e); Cc.o = add2(Tp.o, Tc.o);
+            const uint32_t Be = add2(Cp.e, Cc.e), Bo = add2(Cp.o, Cc.o);
+            Hp = Hc; Ap = Ac; Tp = Tc; Cp = Cc;
+            be = __builtin_amdgcn_perm(0u, Be, 0x0c030c01u);        // the high byte of each half = B >> 8
+            bo = __builtin_amdgcn_perm(0u, Bo, 0x0c030c01u);
             const int bv = v - 2;
             if (INTER && a.blur_out && bv >= y0 && bv < y1) {
                 if (inimg && emits) *reinterpret_cast<uint32_t *>(a.blur_out + (size_t)f * W * H + (size_t)bv * W + px) = be | (bo << 8);
             }
+        } else if constexpr (PACKED_GRAY) {
+            be = gray.e & M8;
+            bo = (gray.e >> 8) & M8;
         } else {
-            be = G & M8;
-            bo = (G >> 8) & M8;
+            be = gray.e;
+            bo = gray.o;
         }
         if (has_border) {       // replicate: column -1 copies column 0, column W copies column W-1
+            asm volatile("");
             const uint32_t r = from_right(be), l = from_left(bo);
             if (lb) bo = (bo & 0x0000FFFFu) | (r << 16);
             if (rb) be = (be & 0xFFFF0000u) | (l >> 16);
         }
 
-        // ---- Sobel, horizontal part of row b = v - DB -------------------------------------------
+        // ---- Sobel, horizontal part of row b: d = b(x+1) - b(x-1) (signed), s = b(x-1) + 2 b(x) + b(x+1) ------
+        const int b_row = v - DB;
+        Pair Dc;
         {
             const uint32_t le = alignbyte(bo, from_left(bo), 2);    // (px-1, px1): left neighbours of the e pixels
             const uint32_t ro = alignbyte(from_right(be), be, 2);   // (px2, px4): right neighbours of the o pixels
-            Dw[P].e = pksub(bo, le);
-            Dw[P].o = pksub(ro, be);
-            Sw[P].e = pkmad2(be, pkadd(le, bo));
-            Sw[P].o = pkmad2(bo, pkadd(be, ro));
+            Dc.e = pksub(bo, le);
+            Dc.o = pksub(ro, be);
+            Sw[P].e = pkmad2(be, le + bo);
+            Sw[P].o = pkmad2(bo, be + ro);
         }
+        // (the empty asm statements keep these two rare cases scalar branches instead of per-row selects)
+        if (b_row == 0) { asm volatile(""); Dp = Dc; Sw[PREV] = Sw[P]; }             // row -1 replicates row 0
+        if (b_row == H) { asm volatile(""); Dc = Dp; Sw[P] = Sw[PREV]; }             // row H replicates row H-1
 
-        // ---- Sobel, vertical part, and magnitude of row m = b - 1 --------------------------------
-        const int m_row = v - DB - 1;
+        // ---- Sobel, vertical part, and magnitude of row m = b - 1 --------------------------------------------
+        const int m_row = b_row - 1;
         {
-            // (the empty asm statements keep these two rare cases scalar branches instead of per-row selects)
-            if (m_row == 0) { asm volatile(""); Dw[OLD] = Dw[PREV]; Sw[OLD] = Sw[PREV]; }        // replicate above
-            if (m_row == H - 1) { asm volatile(""); Dw[P] = Dw[PREV]; Sw[P] = Sw[PREV]; }        // replicate below
-            DXw[P].e = pkmad2(Dw[PREV].e, pkadd(Dw[OLD].e, Dw[P].e));
-            DXw[P].o = pkmad2(Dw[PREV].o, pkadd(Dw[OLD].o, Dw[P].o));
-            DYw[P].e = pksub(Sw[P].e, Sw[OLD].e);
+            Pair Pc;
+            Pc.e = pkadd(Dp.e, Dc.e); Pc.o = pkadd(Dp.o, Dc.o);     // d(b-1) + d(b)
+            DXw[P].e = pkadd(Pp.e, Pc.e);                           // dx = d(m-1) + 2 d(m) + d(m+1)
+            DXw[P].o = pkadd(Pp.o, Pc.o);
+            DYw[P].e = pksub(Sw[P].e, Sw[OLD].e);                   // dy = s(m+1) - s(m-1)
             DYw[P].o = pksub(Sw[P].o, Sw[OLD].o);
+            Dp = Dc; Pp = Pc;
+            Mw[P].e = pkabs(DXw[P].e) + pkabs(DYw[P].e);            // <= 2040: a plain add cannot carry between the halves
+            Mw[P].o = pkabs(DXw[P].o) + pkabs(DYw[P].o);
             // magnitudes outside the image are zero: whole rows above / below it (rare, a scalar branch) and the
             // lanes left / right of it in the first and last strips
-            Mw[P].e = pkadd(pkabs(DXw[P].e), pkabs(DYw[P].e));
-            Mw[P].o = pkadd(pkabs(DXw[P].o), pkabs(DYw[P].o));
             if (m_row < 0 || m_row >= H) { asm volatile(""); Mw[P].e = 0u; Mw[P].o = 0u; }
-            else if (has_border) { Mw[P].e = inimg ? Mw[P].e : 0u; Mw[P].o = inimg ? Mw[P].o : 0u; }
+            if (has_border) { asm volatile(""); Mw[P].e = inimg ? Mw[P].e : 0u; Mw[P].o = inimg ? Mw[P].o : 0u; }
         }
 
         // ---- non-maximum suppression + thresholds of row n = m - 1 -----------------------------
         const int n_row = m_row - 1;
         if (n_row >= y0 && n_row < y1) {
             const uint32_t ce = Mw[PREV].e, co = Mw[PREV].o;
-            const us2 mx = __builtin_elementwise_max(U2(ce), U2(co));
-            const int mmax = max((int)(R32(mx) & 0xFFFFu), (int)(R32(mx) >> 16));
             uint32_t nib = 0;    // bits 0-3 strong, bits 8-11 weak
-            // only the emitting lanes decide: the halo lanes' magnitudes come from a truncated neighbourhood and
-            // would trigger every row
-            if (__ballot(emits && mmax > a.low) != 0) {
-                // one pair of pixels: m against its two neighbours along the gradient
+            const uint32_t over = or_and(ce + trigK, co + trigK, 0x80008000u);   // bit 15 of a half: its m > low
+            if (__builtin_amdgcn_ballot_w64(over != 0) != 0) {
+                // one pair of pixels: m against its two neighbours along the gradient (all magnitudes biased alike)
                 auto nms = [&](uint32_t m, uint32_t dx, uint32_t dy, uint32_t cl, uint32_t cr, uint32_t ul, uint32_t uc,
-                               uint32_t ur, uint32_t dl, uint32_t dc, uint32_t dr, uint32_t &sbit, uint32_t &wbit) {
-                    const uint32_t ax = pkabs(dx), ay = pkabs(dy);
-                    const uint32_t q = R32((U2(ax) * (unsigned short)53 + ((U2(ax) * (unsigned short)5) >> (unsigned short)8)) >> (unsigned short)7);
-                    const uint32_t hz = pkadd(q, pknz(ax));
-                    const uint32_t vt = pkmad2(ax, q);
+                               uint32_t ur, uint32_t dl, uint32_t dc, uint32_t dr, uint32_t &sflag, uint32_t &wflag) {
+                    const uint32_t ax = pkabs(dx), ay = pkabs(dy);          // <= 1020
+                    const uint32_t ax5 = R32(U2(ax) * (unsigned short)5);
+                    const uint32_t q = (R32(U2(ax) * (unsigned short)53 + U2((ax5 >> 8) & M8)) >> 7) & 0x01FF01FFu;
+                    const uint32_t hz = add2(q, pknz(ax));
+                    const uint32_t vt = add2(add2(ax, ax), q);
                     const uint32_t Hm = pksign(pksub(ay, hz));      // 0xFFFF where |dy| < hz
                     const uint32_t Vm = pksign(pksub(vt, ay));      // 0xFFFF where |dy| > vt
                     const uint32_t Om = pksign(dx ^ dy);            // 0xFFFF where dx, dy differ in sign
                     const uint32_t a1 = bfi(Hm, cl, bfi(Vm, uc, bfi(Om, ur, ul)));
                     const uint32_t a2 = bfi(Hm, cr, bfi(Vm, dc, bfi(Om, dl, dr)));
-                    const uint32_t m2 = pksub(m, Hm | Vm);          // m + 1 on the axes: '>=' there
-                    const uint32_t keep = pkmin(satsub(m, low2), pkmin(satsub(m, a1), satsub(m2, a2)));
-                    const uint32_t strong = pkmin(keep, satsub(m, high2));
-                    sbit = pknz(strong);
-                    wbit = pknz(keep) ^ sbit;
+                    // bit 15 of (m | 0x8000) - 1 - x  <=>  m > x; on the axes the second neighbour is '>=': m + 1 > x
+                    const uint32_t mk = add2k(m, 0x7FFF7FFFu);
+                    const uint32_t mk2 = add2(mk, or_and(Hm, Vm, 0x00010001u));
+                    const uint32_t keep = bitop3<0x80>(sub2k(mk, low2), sub2(mk, a1), sub2(mk2, a2));
+                    const uint32_t fh = sub2k(mk, high2);
+                    sflag = keep & fh;                              // bits 15 and 31
+                    wflag = bitop3<0x30>(keep, fh, 0u);             // keep & ~fh
                 };
                 // magnitudes of the neighbouring lanes' pixels, for the three rows: .e = left neighbours of the e
                 // pixels (px-1, px1), .o = right neighbours of the o pixels (px2, px4)
@@ -327,7 +414,9 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
                 uint32_t se, we, so, wo;
                 nms(ce, DXw[PREV].e, DYw[PREV].e, Nw[PREV].e, co, Nw[OLD].e, Mw[OLD].e, Mw[OLD].o, Nw[P].e, Mw[P].e, Mw[P].o, se, we);
                 nms(co, DXw[PREV].o, DYw[PREV].o, ce, Nw[PREV].o, Mw[OLD].e, Mw[OLD].o, Nw[OLD].o, Mw[P].e, Mw[P].o, Nw[P].o, so, wo);
-                const uint32_t xs = se | (so << 1), xw = we | (wo << 1);   // bits 0,1 = px0,px1; bits 16,17 = px2,px3
+                // flags sit in bits 15 (px0 / px1) and 31 (px2 / px3): strong nibble in bits 0-3, weak in bits 8-11
+                const uint32_t xs = and_or(se >> 15, 0x00010001u, (so >> 14) & 0x00020002u);
+                const uint32_t xw = and_or(we >> 15, 0x00010001u, (wo >> 14) & 0x00020002u);
                 nib = ((xs | (xs >> 14)) & 0xFu) | (((xw | (xw >> 14)) & 0xFu) << 8);
                 // two lanes make a byte of each plane: odd lane 2i+1 takes lane 2i+2's nibble
                 nib |= from_right(nib) << 4;
@@ -344,8 +433,10 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     int v = y0 - (DB + 2);
     load_row(v, L[0]); load_row(v + 1, L[1]); load_row(v + 2, L[2]);
     for (; v <= vend; v += 3) {
-        const uint32_t G0 = gray_row(L[0], v), G1 = gray_row(L[1], v + 1), G2 = gray_row(L[2], v + 2);
-        if (v + 3 <= vend) { load_row(v + 3, L[0]); load_row(v + 4, L[1]); load_row(v + 5, L[2]); }
+        const Pair G0 = gray_row(L[0], v), G1 = gray_row(L[1], v + 1), G2 = gray_row(L[2], v + 2);
+        // unconditional (past the unit's last row the last row is fetched again, from cache): a conditional reload
+        // makes the compiler keep a second copy of the nine registers
+        load_row(min(v + 3, vend), L[0]); load_row(min(v + 4, vend), L[1]); load_row(min(v + 5, vend), L[2]);
         store_row(v - 3 - DB - 2, pend[0], pf[0]); store_row(v - 2 - DB - 2, pend[1], pf[1]); store_row(v - 1 - DB - 2, pend[2], pf[2]);
         pf[0] = load_flag(v - DB - 2); pf[1] = load_flag(v + 1 - DB - 2); pf[2] = load_flag(v + 2 - DB - 2);
         step(Phase<0>{}, v, G0);
