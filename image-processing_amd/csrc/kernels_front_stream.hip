@@ -178,28 +178,24 @@ template <int P> using Phase = std::integral_constant<int, P>;
 // has about 3 KiB of LDS left: one front-end workgroup per CU instead of five.
 // INTER: also store the gray (and blurred) images -- parity runs only; the variant without them keeps their
 // per-lane addresses out of the register budget.
-template <bool BLUR, int GATE, bool INTER>   // GATE: 0 none, 1 the colour gate
-__global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
+// One unit: strip s, rows [y0, y1) of frame f.  Two properties of a unit are compile-time switches, so that the
+// three quarters of the units that have neither carry none of the per-row tests (scalar instructions, which the
+// four SIMDs of a CU share one issue port for):
+//   HB  the strip holds a lane left of column 0 or right of column W - 1 (first and last strip of a frame row)
+//   FE  the unit touches the top or bottom of the frame: rows to load may lie outside it, Sobel rows replicate,
+//       magnitude rows outside the image are zero
+template <bool BLUR, int GATE, bool INTER, bool HB, bool FE>   // GATE: 0 none, 1 the colour gate
+__device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, const int s, const int y0, const int y1) {
     const int *__restrict__ gtab = a.gate_tab;
     const int lane = threadIdx.x & 63;
-    // Workgroups go round-robin over the 8 XCDs, each with its own L2.  Neighbouring strips share the cache lines
-    // their rows meet in (a strip row is 744 bytes, not a multiple of 128) and the plane bytes they write, so
-    // consecutive units are handed to ONE XCD: workgroup b works on logical workgroup (b % 8) * chunk + b / 8.
-    const int wgl = (int)(blockIdx.x & 7u) * a.wg_chunk + (int)(blockIdx.x >> 3);
-    const int u = __builtin_amdgcn_readfirstlane(wgl * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // wave-uniform
-    if (u >= a.nunits) return;
-    const int s = u % a.nstrips;
-    const int sg = (u / a.nstrips) % a.nseg;
-    const int f = u / (a.nstrips * a.nseg);
     const int W = a.g.W, H = a.g.H, TX = a.g.TX;
     const int X0 = STRIP * s - 4;                  // column of lane 0's first pixel
-    const int y0 = sg * a.rows_per_unit, y1 = min(y0 + a.rows_per_unit, H);
     const int px = X0 + 4 * lane;
     const bool inimg = px >= 0 && px < W;
     const bool lb = px == -4;                      // the lane left of column 0 (strip 0 only)
     const int jW = (W - X0) >> 2;                  // the lane that starts at column W
     const bool rb = lane == jW;
-    const bool has_border = __builtin_amdgcn_readfirstlane((int)(X0 < 0 || jW <= 63)) != 0;    // wave-uniform
+    constexpr bool has_border = HB;
     const uint8_t *fsrc = a.src + (size_t)f * 3 * W * H;
     // lanes outside the image load a valid pixel group instead of nothing: what they hold never reaches
     // an output (border lanes are rewritten below, magnitudes outside the image are forced to zero)
@@ -233,36 +229,45 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     // register that never changes, the row's offset in a scalar register -- no vector arithmetic per load.
     const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fsrc), 0, 3 * W * H, 0x00020000);
     auto load_row = [&](int v, uint32_t (&r)[3]) {
-        const int rs = BLUR ? reflect101s(v, H) : (v < 0 ? 0 : (v >= H ? H - 1 : v));
+        const int rs = !FE ? v : BLUR ? reflect101s(v, H) : (v < 0 ? 0 : (v >= H ? H - 1 : v));
         const auto q = __builtin_amdgcn_raw_buffer_load_b96(frame, lane_off, (uint32_t)rs * (uint32_t)(3 * W), 0);
         r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
     };
     // Dirty tracking of the plane rows (rowflags != null; the planes then start all zero and only this kernel and the
-    // hysteresis kernel, which adds strong bits where weak ones are, write them): a strip row whose bytes were zero
-    // last time and are zero now is not stored again.  Most are, and a 31-byte store costs one or two whole sectors.
+    // hysteresis kernel, which adds strong bits where weak ones are, write them): strip rows whose bytes were zero
+    // last time and are zero now are not stored again.  Most are, and a 31-byte store costs one or two whole sectors.
+    // The unit of the bookkeeping is the group of three rows the loop below works in (one flag, one test, up to
+    // three rows stored): per row it cost as much scalar and vector work as a sixth of the arithmetic.  A group's
+    // flag sits at the group's middle row, clamped into the unit (groups differ in that row: see the loop).
     const size_t flag_base = ((size_t)f * a.nstrips + s) * H;
-    auto load_flag = [&](int n_row) -> uint32_t {
-        if (a.rowflags && n_row >= y0 && n_row < y1) return a.rowflags[flag_base + n_row];
+    auto flag_index = [&](int n0) -> size_t { return flag_base + (size_t)min(max(n0 + 1, y0), y1 - 1); };
+    auto load_flag = [&](int n0) -> uint32_t {
+        if (a.rowflags && n0 + 2 >= y0 && n0 < y1) return a.rowflags[flag_index(n0)];
         return 1u;
     };
-    auto store_row = [&](int n_row, uint32_t both, uint32_t pflag) {
-        if (n_row >= y0 && n_row < y1) {
-            const bool nz = __ballot(stores && (both & 0xFFFFu) != 0) != 0;
+    auto store_group = [&](int n0, const uint32_t (&pd)[3], uint32_t pflag) {
+        if (n0 + 2 >= y0 && n0 < y1) {
+            const bool nz = __builtin_amdgcn_ballot_w64(stores && ((pd[0] | pd[1] | pd[2]) & 0xFFFFu) != 0) != 0;
             const bool was = __builtin_amdgcn_readfirstlane(pflag) != 0;
             if (nz || was) {
-                uint8_t *rowS = reinterpret_cast<uint8_t *>(a.planeS) + ((size_t)f * H + n_row) * TX * 8;
-                uint8_t *rowW = reinterpret_cast<uint8_t *>(a.planeW) + ((size_t)f * H + n_row) * TX * 8;
-                if (stores) {
-                    const uint32_t wb = (both >> 8) & 0xFF;
-                    rowS[bi] = (uint8_t)(both & 0xFF);
-                    rowW[bi] = (uint8_t)wb;
-                    if (wb) a.wake[((size_t)f * a.g.TY + (n_row >> 6)) * TX + (bi >> 3)] = 1u;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int n_row = n0 + k;
+                    if (n_row < y0 || n_row >= y1) continue;
+                    uint8_t *rowS = reinterpret_cast<uint8_t *>(a.planeS) + ((size_t)f * H + n_row) * TX * 8;
+                    uint8_t *rowW = reinterpret_cast<uint8_t *>(a.planeW) + ((size_t)f * H + n_row) * TX * 8;
+                    if (stores) {
+                        const uint32_t wb = (pd[k] >> 8) & 0xFF;
+                        rowS[bi] = (uint8_t)(pd[k] & 0xFF);
+                        rowW[bi] = (uint8_t)wb;
+                        if (wb) a.wake[((size_t)f * a.g.TY + (n_row >> 6)) * TX + (bi >> 3)] = 1u;
+                    }
                 }
             }
-            if (a.rowflags && nz != was && lane == 0) a.rowflags[flag_base + n_row] = nz ? 1 : 0;
+            if (a.rowflags && nz != was && lane == 0) a.rowflags[flag_index(n0)] = nz ? 1 : 0;
         }
     };
-    uint32_t pf[3] = {1u, 1u, 1u};                 // flags of the rows the next group top stores
+    uint32_t pf = 1u;                              // flag of the group the next group top stores
 
     const int vend = y1 - 1 + DB + 2;
 
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         uint32_t be, bo;
         if constexpr (BLUR) {
             uint32_t G = gray.e;
-            if (has_border) {   // reflect 101: columns -1,-2 mirror 1,2; columns W,W+1 mirror W-2,W-3
+            if constexpr (has_border) {   // reflect 101: columns -1,-2 mirror 1,2; columns W,W+1 mirror W-2,W-3
                 const uint32_t GR0 = from_right(G), GL0 = from_left(G);
                 if (lb) G = (GR0 & 0x00FF0000u) | ((GR0 << 16) & 0xFF000000u);
                 if (rb) G = ((GL0 >> 16) & 0xFFu) | (GL0 & 0xFF00u);
@@ -335,8 +340,7 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             be = gray.e;
             bo = gray.o;
         }
-        if (has_border) {       // replicate: column -1 copies column 0, column W copies column W-1
-            asm volatile("");
+        if constexpr (has_border) {       // replicate: column -1 copies column 0, column W copies column W-1
             const uint32_t r = from_right(be), l = from_left(bo);
             if (lb) bo = (bo & 0x0000FFFFu) | (r << 16);
             if (rb) be = (be & 0xFFFF0000u) | (l >> 16);
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             Sw[P].o = pkmad2(bo, be + ro);
         }
         // (the empty asm statements keep these two rare cases scalar branches instead of per-row selects)
-        if (b_row == 0) { asm volatile(""); Dp = Dc; Sw[PREV] = Sw[P]; }             // row -1 replicates row 0
-        if (b_row == H) { asm volatile(""); Dc = Dp; Sw[P] = Sw[PREV]; }             // row H replicates row H-1
+        if (FE && b_row == 0) { asm volatile(""); Dp = Dc; Sw[PREV] = Sw[P]; }       // row -1 replicates row 0
+        if (FE && b_row == H) { asm volatile(""); Dc = Dp; Sw[P] = Sw[PREV]; }       // row H replicates row H-1
 
         // ---- Sobel, vertical part, and magnitude of row m = b - 1 --------------------------------------------
         const int m_row = b_row - 1;
@@ -371,13 +375,15 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             Mw[P].o = pkabs(DXw[P].o) + pkabs(DYw[P].o);
             // magnitudes outside the image are zero: whole rows above / below it (rare, a scalar branch) and the
             // lanes left / right of it in the first and last strips
-            if (m_row < 0 || m_row >= H) { asm volatile(""); Mw[P].e = 0u; Mw[P].o = 0u; }
-            if (has_border) { asm volatile(""); Mw[P].e = inimg ? Mw[P].e : 0u; Mw[P].o = inimg ? Mw[P].o : 0u; }
+            if (FE && (m_row < 0 || m_row >= H)) { asm volatile(""); Mw[P].e = 0u; Mw[P].o = 0u; }
+            if constexpr (has_border) { Mw[P].e = inimg ? Mw[P].e : 0u; Mw[P].o = inimg ? Mw[P].o : 0u; }
         }
 
         // ---- non-maximum suppression + thresholds of row n = m - 1 -----------------------------
-        const int n_row = m_row - 1;
-        if (n_row >= y0 && n_row < y1) {
+        // (not for the rows above y0 the unit warms up on: their half-filled windows look like strong gradients and
+        // would run the NMS block every time.  The two rows below y1 - 1 it drains on do come through here: what
+        // they yield is never stored, and their occasional NMS block costs less than a second test per row.)
+        if (m_row > y0) {
             const uint32_t ce = Mw[PREV].e, co = Mw[PREV].o;
             uint32_t nib = 0;    // bits 0-3 strong, bits 8-11 weak
             const uint32_t over = or_and(ce + trigK, co + trigK, 0x80008000u);   // bit 15 of a half: its m > low
@@ -437,13 +443,38 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
         // unconditional (past the unit's last row the last row is fetched again, from cache): a conditional reload
         // makes the compiler keep a second copy of the nine registers
         load_row(min(v + 3, vend), L[0]); load_row(min(v + 4, vend), L[1]); load_row(min(v + 5, vend), L[2]);
-        store_row(v - 3 - DB - 2, pend[0], pf[0]); store_row(v - 2 - DB - 2, pend[1], pf[1]); store_row(v - 1 - DB - 2, pend[2], pf[2]);
-        pf[0] = load_flag(v - DB - 2); pf[1] = load_flag(v + 1 - DB - 2); pf[2] = load_flag(v + 2 - DB - 2);
+        store_group(v - 3 - DB - 2, pend, pf);
+        pf = load_flag(v - DB - 2);
         step(Phase<0>{}, v, G0);
         step(Phase<1>{}, v + 1, G1);
         step(Phase<2>{}, v + 2, G2);
     }
-    store_row(v - 3 - DB - 2, pend[0], pf[0]); store_row(v - 2 - DB - 2, pend[1], pf[1]); store_row(v - 1 - DB - 2, pend[2], pf[2]);
+    store_group(v - 3 - DB - 2, pend, pf);
+}
+
+template <bool BLUR, int GATE, bool INTER>
+__global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
+    // Workgroups go round-robin over the 8 XCDs, each with its own L2.  Neighbouring strips share the cache lines
+    // their rows meet in (a strip row is 744 bytes, not a multiple of 128) and the plane bytes they write, so
+    // consecutive units are handed to ONE XCD: workgroup b works on logical workgroup (b % 8) * chunk + b / 8.
+    const int wgl = (int)(blockIdx.x & 7u) * a.wg_chunk + (int)(blockIdx.x >> 3);
+    const int u = __builtin_amdgcn_readfirstlane(wgl * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // wave-uniform
+    if (u >= a.nunits) return;
+    const int s = u % a.nstrips;
+    const int sg = (u / a.nstrips) % a.nseg;
+    const int f = u / (a.nstrips * a.nseg);
+    const int H = a.g.H;
+    const int y0 = sg * a.rows_per_unit, y1 = min(y0 + a.rows_per_unit, H);
+    constexpr int DB = BLUR ? 2 : 0;
+    const bool hb = STRIP * s - 4 < 0 || ((a.g.W - (STRIP * s - 4)) >> 2) <= 63;
+    const bool fe = y0 == 0 || y1 + DB + 1 >= H;        // rows y0 - DB - 2 .. y1 + DB + 1 are loaded
+    if (hb) {
+        if (fe) front_unit<BLUR, GATE, INTER, true, true>(a, f, s, y0, y1);
+        else front_unit<BLUR, GATE, INTER, true, false>(a, f, s, y0, y1);
+    } else {
+        if (fe) front_unit<BLUR, GATE, INTER, false, true>(a, f, s, y0, y1);
+        else front_unit<BLUR, GATE, INTER, false, false>(a, f, s, y0, y1);
+    }
 }
 
 }  // namespace
