@@ -180,7 +180,7 @@ struct Work {
         HIP_TRY(hipMemset(rowcount.p, 0, sizeof(int) * (size_t)B * H));
         if ((rc = npoints.alloc(B))) return rc;
         if ((rc = segcount.alloc(B))) return rc;
-        if ((rc = status.alloc(2))) return rc;
+        if ((rc = status.alloc(3))) return rc;
         if ((rc = fallback.alloc(B))) return rc;
         return LC_OK;
     }
@@ -803,7 +803,7 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
     const int na = wk.hg.numangle, nr = wk.hg.numrho;
     if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
     if ((rc = points_from_bytes(ctx, nullptr))) return rc;
-    HIP_TRY(hipMemsetAsync(wk.status.p, 0, 2 * sizeof(int), ctx->stream));
+    HIP_TRY(hipMemsetAsync(wk.status.p, 0, 3 * sizeof(int), ctx->stream));
     const int line_length = (int)lrint(min_line_length), line_gap = (int)lrint(max_line_gap);
     const bool fast = launch_ppht_fast(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, threshold, line_length,
                                        line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, RNG_TABLE,
@@ -880,6 +880,14 @@ struct lc_pipe {
     // second one gained nothing there); LANECV_LINES_STREAMS overrides the count.
     std::vector<hipStream_t> st_lines_more;
     unsigned lines_turn = 0;
+    bool fuse_vote = true;        // HoughLinesP's kernel also produces the full-vote accumulator (in LDS, before its own)
+    // HoughLinesP with half a CU's LDS per frame, so that two frames -- of two batches, on two streams -- share a CU:
+    // the kernel is one sequential wavefront per frame and leaves most of a CU idle.  For frame sizes whose working
+    // set usually fits (up to about 2.5 megapixels; 1080p road frames take 55 - 60 KiB).
+    // A frame that needs more falls to the slow general kernel; lc_pipe_wait sees it (status word 2) and the next
+    // `ppht_full_for` batches get a whole CU's LDS per frame again, after which the half size is tried anew.
+    bool ppht_two_per_cu = false;
+    int ppht_full_for = 0;
     int shared_queues = 0;        // streams of this layout that found no hardware queue of their own (lc_pipe_create)
 
     // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs).  The HoughLinesP
@@ -914,7 +922,7 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     // produces it on the side (its helper wavefronts, from the same LDS-resident set-up) and the vote kernel
     // only runs for the frames that kernel flags; it sits between the two HoughLinesP steps because the
     // general one permutes the point list.  Stage times: VOTE = that flagged launch, LINES = both steps.
-    const bool vote_fused = p.want_accumulator && p.want_segments;
+    const bool vote_fused = p.want_accumulator && p.want_segments && pp->fuse_vote;
     if (p.want_accumulator && !vote_fused)
         launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, nullptr, es);
     if (!vote_fused) (void)hipEventRecord(s.ev[EV_VOTE], es);
@@ -928,17 +936,20 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
     const lc_pipe_params &p = pp->p;
     const int n = s.nframes;
     hipStream_t es = pp->st_post;
-    const bool vote_fused = p.want_accumulator && p.want_segments;
+    const bool vote_fused = p.want_accumulator && p.want_segments && pp->fuse_vote;
     hipStream_t ls = es;   // the stream the batch finishes on
     if (p.want_segments) {
         const unsigned turn = pp->lines_turn++ % (unsigned)(1 + pp->st_lines_more.size());
         ls = turn ? pp->st_lines_more[turn - 1] : pp->st_lines;
-        if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[EV_POINTS], 0);
+        // (a stand-alone vote kernel reads the point list the general kernel permutes: behind it, then)
+        if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[(p.want_accumulator && !vote_fused) ? EV_VOTE : EV_POINTS], 0);
         if (ls != es && after) (void)hipStreamWaitEvent(ls, after, 0);
         (void)hipEventRecord(s.ev[EV_LSTART], ls);
         const bool fast = launch_ppht_fast(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
                                            p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
-                                           w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls);
+                                           w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls,
+                                           (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false);
+        if (pp->ppht_full_for > 0) pp->ppht_full_for--;
         // one launch for the frames the fast kernel flagged: their full-vote accumulator first (the general kernel
         // permutes the point list), then HoughLinesP with all state in global memory.  No events in between: every
         // packet on this stream is on the critical path.
@@ -1051,6 +1062,9 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     pp->high = (int)std::floor(t2);
     pp->line_length = (int)lrint(p.min_line_length);
     pp->line_gap = (int)lrint(p.max_line_gap);
+    if (const char *fv = getenv("LANECV_VOTE_FUSED")) pp->fuse_vote = fv[0] != '0';
+    pp->ppht_two_per_cu = p.want_segments && (size_t)p.width * p.height <= 2600000 && p.nslots >= 3;
+    if (const char *tp = getenv("LANECV_PPHT_TWO_PER_CU")) pp->ppht_two_per_cu = tp[0] != '0';   // diagnostics
 
     pp->src_w = p.src_width > 0 ? p.src_width : p.width;
     pp->src_h = p.src_height > 0 ? p.src_height : p.height;
@@ -1152,7 +1166,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             hipDeviceProp_t prop;
             int want = 1;
             if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
-                want = std::max(1, std::min(std::min(prop.multiProcessorCount / p.max_batch, p.nslots - 1), 3));
+                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * prop.multiProcessorCount / p.max_batch, p.nslots - 1), 3));
             const char *ns = getenv("LANECV_LINES_STREAMS");
             if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
             for (int k = 1; k < want; k++) {
@@ -1312,6 +1326,7 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     }
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
+    if (p.want_segments && s->h_status[2]) pipe->ppht_full_for = 64;   // a frame outgrew half a CU's LDS (see lc_pipe)
     if (p.want_segments || p.want_accumulator || p.want_points) {
         if (s->h_status[0])
             return fail(LC_ECAP, "a frame holds more edge points than the pipeline keeps per frame (%d): its point list, accumulator and "

@@ -99,7 +99,8 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 // kernel: those with weak pixels), then repeats over the tiles whose neighbours gained a strong border pixel
 // until a round flags none; rounds[f] receives the rounds frame f needed.  wake holds two arrays of
 // nframes * tiles flags (the second all zero on entry); both are all zero on exit.
-// status (may be null): two words this kernel zeroes; the kernels behind it on the stream raise them with plain stores
+// status (may be null): three words this kernel zeroes; the kernels behind it on the stream raise them with plain stores
+// ([0], [1]: launch_points; [2]: a frame did not fit the LDS the fast HoughLinesP kernel was launched with)
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st, int *status = nullptr);
 // roi_bits: one plane shared by all frames, or nullptr
@@ -141,7 +142,10 @@ int lds_atomic_probe(int run, bool returning, int blocks, int iters, int *sink, 
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
-                      int rng_len, int32_t *acc_full, hipStream_t st);
+                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes = 0, bool only_flagged = false);
+// lds_bytes: dynamic LDS per frame (0 = the most a CU gives one workgroup); with ppht_lds_half() two frames share a
+// CU, and a second launch with only_flagged and the full size takes the frames that needed more
+int ppht_lds_half();
 void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                          const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
                          int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, const int *flags,

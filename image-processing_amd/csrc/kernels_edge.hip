@@ -367,7 +367,10 @@ __device__ __forceinline__ int nb_tile(const Geo &g, int ty, int tx, int k) {
 // per frame, swapped every round) and the kernel keeps 4 bytes of LDS, so it can share a CU with kernels of
 // other batches that fill the LDS.  A wavefront reads 64 flags at once, lane l that of tile 16 l + wave:
 // neighbouring tiles (a lane marking crosses several in a row) go to different wavefronts.
-constexpr int HC_THREADS = 1024, HC_WAVES = HC_THREADS / 64;
+#ifndef LC_HC_THREADS
+#define LC_HC_THREADS 1024
+#endif
+constexpr int HC_THREADS = LC_HC_THREADS, HC_WAVES = HC_THREADS / 64;
 __device__ __forceinline__ uint32_t ldF(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__re
                                                            uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
                                                            int *__restrict__ rounds_out, int *__restrict__ status) {
     __shared__ int any;
-    if (status && blockIdx.x == 0 && threadIdx.x == 0) status[0] = status[1] = 0;   // raised by the kernels behind this one
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) status[0] = status[1] = status[2] = 0;   // raised by the kernels behind this one
     hysteresis_frame(g, blockIdx.x, planeS, planeW, wakeA, wakeB, rounds_out, any);
 }
 

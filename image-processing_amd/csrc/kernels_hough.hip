@@ -8,6 +8,7 @@
 // and __float2int_rn.  The trig table and the walk steps come from the host.
 #include "common.h"
 #include <climits>
+#include <cstdlib>
 #include <algorithm>
 #include <mutex>
 
@@ -23,7 +24,10 @@ __device__ __forceinline__ int rho_bin(int x, int y, float c, float s, int half)
 // rows; the per-row counts give its total (and are cleared: this kernel is their last reader), a scan over
 // the 16 totals its first position, and then the band's plane words -- contiguous in memory and already in
 // scan order -- are taken 64 at a time: popcount, wave scan, scatter.  Bands without points leave at once.
-constexpr int POINTS_WAVES = 16;
+#ifndef LC_POINTS_WAVES
+#define LC_POINTS_WAVES 16
+#endif
+constexpr int POINTS_WAVES = LC_POINTS_WAVES;
 
 __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint64_t *__restrict__ rowplane,
                                                                int *__restrict__ rowcount, uint32_t *__restrict__ nz, int nz_cap,
@@ -235,6 +239,10 @@ __device__ long long g_frame_cycles[1024];   // consumer loop and whole kernel (
 #define PPHT_Q 4   // points voting speculatively per group in the LDS path
 #endif
 constexpr int LDS_BIAS = 0x4000;   // offset of the 16-bit accumulator bins kept in LDS
+// Dynamic LDS of the fast HoughLinesP kernel.  MAX: a frame alone on a CU (152 of its 160 KiB; the rest covers the
+// kernel's own static tables and the little the short kernels of other batches need beside it).  HALF: two frames
+// per CU -- 1080p road frames need 55 - 60 KiB -- so that the kernels of two batches run side by side.
+constexpr int PPHT_LDS_MAX = 152 * 1024, PPHT_LDS_HALF = 72 * 1024;
 
 // Per-frame constants of one HoughLinesP run.
 struct Ppht {
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
                                                    int32_t *__restrict__ seg_all, int seg_cap, int *__restrict__ seg_count,
                                                    int *__restrict__ status, int *__restrict__ fallback, int lds_points,
                                                    const uint32_t *__restrict__ rng_out, int lds_bytes,
-                                                   int32_t *__restrict__ acc_full) {
+                                                   int32_t *__restrict__ acc_full, int only_flagged) {
     extern __shared__ __align__(16) uint32_t lds32[];
     __shared__ int progress;
     __shared__ Jobs jobs;
@@ -718,7 +726,6 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     __shared__ int s_part[PPHT_THREADS];
     __shared__ uint32_t a_base[64], a_rfix[64], a_wid[64];
     __shared__ int a_rmin[64];
-    __shared__ int vote_done;
     __shared__ AngleEntry s_tab[64];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef LC_STAMPS
@@ -726,6 +733,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     const long long t_kernel0 = STAMP();
 #endif
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
+    if (only_flagged && !(fallback[f] & 1)) return;   // second launch (more LDS per frame): the frames the first one left
     const int n = npoints[f];
     if (n > nz_cap) {
         if (tid == 0) { seg_count[f] = 0; fallback[f] = 2; status[0] = 1; }
@@ -757,11 +765,11 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     const size_t rt_off = ((size_t)n + 3) & ~(size_t)3;          // 16-byte aligned
     uint32_t *rowtab = lds32 + rt_off;
     if ((rt_off + 4 * (size_t)nrows) * 4 > (size_t)lds_bytes) {  // (the row table alone does not fit)
-        if (tid == 0) fallback[f] = 3;
+        if (tid == 0) { fallback[f] = 3; status[2] = 1; }
         return;
     }
     if (tid == 0) {
-        progress = 0; vote_done = 0;
+        progress = 0;
         jobs.seq = 0; jobs.done = 0;
         s_xmin = INT_MAX; s_xmax = 0;
     }
@@ -841,32 +849,21 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     const int accbins = s_accbins, maskwords = s_maskwords;
     const size_t acc_off = rt_off + 4 * (size_t)nrows;                             // in 32-bit words, 16-byte aligned
     const size_t acc_words = ((size_t)accbins + 1) / 2;
-    // the full-vote accumulator, when wanted, is a second array of the same compact shape (plain 16-bit counts)
-    bool full_here = acc_full != nullptr;
-    size_t facc_off = (acc_off + acc_words + 1) & ~(size_t)1;
-    size_t mask_off = full_here ? ((facc_off + acc_words + 1) & ~(size_t)1) : facc_off;
-    if (full_here && (mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes) {   // no room for it: the vote kernel does this frame
-        full_here = false;
-        mask_off = facc_off;
-    }
+    // The full-vote accumulator, when wanted, is made first, in the same compact array, by all wavefronts: every point
+    // votes once per angle (one angle per lane, plain 16-bit counts: there are fewer than 2^14 points), the array goes
+    // out in OpenCV's [angle][rho] shape and is then handed to HoughLinesP.  A few per cent of the frame's time (the
+    // sequential loop below dominates), against a second array of the same size that would keep a CU's LDS from
+    // holding two frames.
+    const size_t mask_off = (acc_off + acc_words + 1) & ~(size_t)1;
     if ((mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes) {
-        if (tid == 0) fallback[f] = 3;   // does not fit the CU's LDS: the general kernel (and the vote kernel) take the frame
+        if (tid == 0) { fallback[f] = 3; status[2] = 1; }   // does not fit: the general kernel (and its vote) take the frame
         return;
     }
-    if (tid == 0) fallback[f] = (acc_full != nullptr && !full_here) ? 2 : 0;
-    if (full_here)
-        for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[facc_off + i] = 0;
+    if (tid == 0) fallback[f] = 0;
     c.lacc = reinterpret_cast<int16_t *>(lds32 + acc_off);
     c.lmask = reinterpret_cast<uint64_t *>(lds32 + mask_off);
     c.rowtab = reinterpret_cast<const uint4 *>(rowtab); c.ymin = ymin; c.nrows = nrows;
     c.ltab = s_tab;
-    for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[acc_off + i] = (uint32_t)LDS_BIAS * 0x10001u;
-    for (int r = wave; r < nrows; r += PPHT_THREADS / 64) {     // lane = image word of the row
-        const uint4 e = c.rowtab[r];
-        uint32_t widx;
-        if (row_word(e, lane, widx)) c.lmask[widx] = c.mask[(size_t)(ymin + r) * c.TX + lane];
-    }
-    __syncthreads();
     // lane l votes for angle l; lanes past the last angle add zero to a harmless bin instead of branching
     VoteLane vl;
     vl.c = vl.s = 0.f;
@@ -876,44 +873,48 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     vl.rfix = a_rfix[lane];
     vl.wid = a_wid[lane];
     vl.words = reinterpret_cast<uint32_t *>(c.lacc);
-    if (wave >= 2) {                // helpers: the full-vote accumulator first, then vote removal for accepted lines
-        if (full_here) {
-            // every point votes once per angle (one angle per lane), straight from the sorted list in memory --
-            // the LDS copy is being permuted by the producer.  Counts stay below 2^14: plain 16-bit halves.
-            uint32_t *fw = lds32 + facc_off;
-            const int part = wave - 2, nparts = PPHT_THREADS / 64 - 2;
-            for (int p0 = part * 64; p0 < n; p0 += nparts * 64) {
-                const int m = min(64, n - p0);
-                const uint32_t ptv = lane < m ? nz[p0 + lane] : 0u;
-                const float fjv = (float)(ptv & 0xFFFF), fiv = (float)(ptv >> 16);
-                for (int t = 0; t < m; t++) {
-                    const float fj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), t));
-                    const float fi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), t));
-                    uint32_t widx, sh, over;
-                    vote_bin(vl, fj, fi, widx, sh, over);
-                    atomicAdd(&fw[widx], vl.one << sh);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) atomicAdd(&vote_done, 1);
-            while (*(volatile int *)&vote_done < nparts) __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // write-out in OpenCV's [angle][rho] shape: zeros outside the reachable range of an angle
-            for (int a = part; a < numangle; a += nparts) {
-                const int rmin = a_rmin[a], wid = (int)a_wid[a];
-                const uint32_t base = a_base[a];
-                int32_t *out = acc_full + ((size_t)f * numangle + a) * numrho;
-                for (int r = lane; r < numrho; r += 64) {
-                    const int k = r - rmin;
-                    int v = 0;
-                    if ((unsigned)k <= (unsigned)wid) {
-                        const uint32_t bin = base + (uint32_t)k;
-                        v = (int)((fw[bin >> 1] >> ((bin & 1u) << 4)) & 0xFFFFu);
-                    }
-                    out[r] = v;
-                }
+    if (acc_full != nullptr) {
+        uint32_t *fw = vl.words;
+        for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) fw[i] = 0;
+        __syncthreads();
+        for (int p0 = wave * 64; p0 < n; p0 += PPHT_WAVES * 64) {
+            const int m = min(64, n - p0);
+            const uint32_t ptv = lane < m ? lnz[p0 + lane] : 0u;
+            const float fjv = (float)(ptv & 0xFFFF), fiv = (float)(ptv >> 16);
+            for (int t = 0; t < m; t++) {
+                const float fj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), t));
+                const float fi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), t));
+                uint32_t widx, sh, over;
+                vote_bin(vl, fj, fi, widx, sh, over);
+                atomicAdd(&fw[widx], vl.one << sh);
             }
         }
+        __syncthreads();
+        // write-out in OpenCV's [angle][rho] shape: zeros outside the reachable range of an angle
+        for (int a = wave; a < numangle; a += PPHT_WAVES) {
+            const int rmin = a_rmin[a], wid = (int)a_wid[a];
+            const uint32_t base = a_base[a];
+            int32_t *out = acc_full + ((size_t)f * numangle + a) * numrho;
+            for (int r = lane; r < numrho; r += 64) {
+                const int k = r - rmin;
+                int v = 0;
+                if ((unsigned)k <= (unsigned)wid) {
+                    const uint32_t bin = base + (uint32_t)k;
+                    v = (int)((fw[bin >> 1] >> ((bin & 1u) << 4)) & 0xFFFFu);
+                }
+                out[r] = v;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[acc_off + i] = (uint32_t)LDS_BIAS * 0x10001u;
+    for (int r = wave; r < nrows; r += PPHT_THREADS / 64) {     // lane = image word of the row
+        const uint4 e = c.rowtab[r];
+        uint32_t widx;
+        if (row_word(e, lane, widx)) c.lmask[widx] = c.mask[(size_t)(ymin + r) * c.TX + lane];
+    }
+    __syncthreads();
+    if (wave >= 2) {                // helpers: vote removal for accepted lines
         job_serve(&jobs, wave - 1, vl, lane);
         return;
     }
@@ -1129,7 +1130,8 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
     // workgroups fill a CU's wave slots), so that a workgroup's pass over the frame's points serves more angles;
     // 32 KiB was slower (0.054 against 0.040 ms for 256 1080p frames), 8 KiB too (0.079)
     const int budget = 16 * 1024;
-    const int apg = flags ? vote_apg(numangle, numrho, groups) : vote_apg(numangle, numrho, groups, budget);
+    static const char *vb_env = getenv("LANECV_VOTE_LDS_KB");
+    const int apg = flags ? vote_apg(numangle, numrho, groups) : vote_apg(numangle, numrho, groups, vb_env ? atoi(vb_env) * 1024 : budget);
     size_t lds = (size_t)apg * (numrho + 1) * 4;
     static LdsOptIn optin;
     (void)optin.ensure(reinterpret_cast<const void *>(k_vote), lds);
@@ -1139,24 +1141,25 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
                        numrho, apg, acc, flags);
 }
 
+int ppht_lds_half() { return PPHT_LDS_HALF; }
+
 // HoughLinesP in two steps, so that the caller can put the flagged vote kernel between them (the general
 // kernel permutes the point list in place).  flags[f]: bit 0 = the general kernel must do frame f,
 // bit 1 = the frame's full-vote accumulator (acc_full, may be null) was not produced here.
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
-                      int rng_len, int32_t *acc_full, hipStream_t st) {
-    // points, compact int16 accumulator(s) and the mask spans in LDS; a frame whose set does not fit (the
-    // kernel decides, per frame) is flagged.  The kernel may take 152 of the CU's 160 KiB: the rest covers
-    // its own static tables and the little LDS the short kernels of the next batch need beside it.
+                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged) {
+    // points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not fit lds_bytes (the
+    // kernel decides, per frame) is flagged.
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
-    const int lds_bytes = 152 * 1024;
+    if (lds_bytes <= 0 || lds_bytes > PPHT_LDS_MAX) lds_bytes = PPHT_LDS_MAX;
     const int lds_points = std::min(rng_len, LDS_BIAS - 1);
     static LdsOptIn optin;
-    if (optin.ensure(reinterpret_cast<const void *>(k_ppht_fast), (size_t)lds_bytes) != hipSuccess) return false;
+    if (optin.ensure(reinterpret_cast<const void *>(k_ppht_fast), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
     hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(PPHT_THREADS), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                        numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                       lds_bytes, acc_full);
+                       lds_bytes, acc_full, only_flagged ? 1 : 0);
     return true;
 }
 
