@@ -122,6 +122,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
     ap.add_argument("--same-input", action="store_true", help="resubmit one device batch every step (the round-1 figure)")
+    ap.add_argument("--clips", type=int, default=0,
+                    help="BASELINE configs[4] shape: this many clips sharded clip-major over the ranks (0: one clip of "
+                         "steps x batch frames per rank)")
+    ap.add_argument("--frames-per-clip", type=int, default=2048)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,11 +140,24 @@ def main():
 
     import numpy as np
     host_threads = min(16, os.cpu_count() or 1)
-    # two distinct batches of the rank's clip (frames t = 0..batch-1 and batch..2*batch-1), alternated per submit: a
-    # slot then never sees the frames it processed last time, so nothing of the pipeline's change tracking (it
-    # rewrites only what differs from the slot's previous batch) is flattered by identical input
+    sys.path.insert(0, os.path.join(ROOT, "image-processing_amd"))
+    from lanecv import shard
+    # Default: one clip per rank (clip 100 + rank), `steps` batches long.  --clips C: C clips of --frames-per-clip
+    # frames, clip c on rank c mod world (shard.clip_assignment), each rank working through its clips one after
+    # the other.  Either way a clip is fed from two distinct device batches that alternate, so that a slot never sees
+    # the frames it processed last time: nothing of the pipeline's change tracking (it rewrites only what differs
+    # from the slot's previous batch) is flattered by identical input.
     nbatches = 1 if args.same_input else 2
-    frames = make_frames(100 + rank, nbatches * batch, host_threads)
+    if args.clips > 0:
+        my_clips = shard.clip_assignment(args.clips, world, rank)
+        frames_per_clip = args.frames_per_clip
+        distinct = min(64, nbatches * batch)       # frames generated per clip; tiled to the two batches on the device
+    else:
+        my_clips = [rank]
+        frames_per_clip = args.steps * batch
+        distinct = nbatches * batch
+    host_clips = [make_frames(100 + c, distinct, host_threads) for c in my_clips]
+    frames = host_clips[0][:batch] if my_clips else make_frames(100, batch, host_threads)
 
     import torch                       # first: liblanecv.so then binds to the HIP runtime torch loaded
     import torch.distributed as dist
@@ -168,7 +185,7 @@ def main():
         if rehearse:
             print("[rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
 
-    from lanecv import _abi, shard
+    from lanecv import _abi
     from lanecv.pipeline import LanePipeline, Recipe
     rec = Recipe.north_star(W, H)
     if os.environ.get("LANECV_BENCH_START_AT"):       # diagnostics: several benches on one GPU starting in step
@@ -176,12 +193,22 @@ def main():
             time.sleep(0.0005)
     pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=args.slots, seg_capacity=SEG_CAP, device=local_rank)
 
-    dev_frames = torch.from_numpy(frames).cuda()                 # inputs resident in HBM
-    torch.cuda.synchronize()
-    ptr = dev_frames.data_ptr()
+    # inputs resident in HBM: per clip `nbatches` batches of `batch` frames
     frame_bytes = 3 * W * H
-    ptrs = [ptr + b * batch * frame_bytes for b in range(nbatches)]
-    frames = frames[:batch]
+    dev_clips = []
+    for hc in host_clips:
+        d = torch.from_numpy(hc).cuda()
+        if len(hc) < nbatches * batch:           # tile the distinct frames, each batch in another order
+            idx = torch.cat([(torch.arange(batch) * 5 + 11 * b) % len(hc) for b in range(nbatches)]).cuda()
+            d = d[idx].contiguous()
+        dev_clips.append(d)
+    torch.cuda.synchronize()
+    ptr = dev_clips[0].data_ptr() if dev_clips else None
+    # the jobs of this rank in order: (device pointer, frames) batch after batch, clip after clip
+    jobs = []
+    for d in dev_clips:
+        for k in range((frames_per_clip + batch - 1) // batch):
+            jobs.append((d.data_ptr() + (k % nbatches) * batch * frame_bytes, min(batch, frames_per_clip - k * batch)))
     note("pipeline and frames ready")
 
     results = {}
@@ -189,38 +216,44 @@ def main():
                    "edge": _abi.STAGE_EDGE, "points": _abi.STAGE_POINTS, "vote": _abi.STAGE_VOTE,
                    "lines": _abi.STAGE_LINES, "total": _abi.STAGE_TOTAL}
 
-    def run(steps, collect_stages=None):
+    def run(job_list, collect_stages=None, keep=None):
+        """Pushes the jobs through the slots in order; keep (a list) receives each batch's (rows, counts) unpadded."""
         inflight = []
-        for k in range(steps):
-            slot = k % args.slots
-            if len(inflight) == args.slots:
-                s = inflight.pop(0)
-                results[s] = pipe.wait(s)
-                if collect_stages is not None:
-                    collect_stages.append({n: pipe.stage_ms(s, i) for n, i in stage_names.items()})
-            # the batch changes with every pass over the slots: a slot's consecutive batches differ
-            pipe.submit_device(slot, ptrs[(k // args.slots) % nbatches], batch)
-            inflight.append(slot)
-        for s in inflight:
-            results[s] = pipe.wait(s)
+
+        def finish(s):
+            seg, cnt = pipe.wait(s)
+            results[s] = (seg, cnt)
+            if keep is not None:
+                keep.append((shard.compact(seg, cnt), cnt))
             if collect_stages is not None:
                 collect_stages.append({n: pipe.stage_ms(s, i) for n, i in stage_names.items()})
+
+        for k, (p_dev, n) in enumerate(job_list):
+            slot = k % args.slots
+            if len(inflight) == args.slots:
+                finish(inflight.pop(0))
+            pipe.submit_device(slot, p_dev, n)
+            inflight.append(slot)
+        for s in inflight:
+            finish(s)
 
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
 
-    run(args.warmup)
+    if jobs:
+        run([jobs[k % len(jobs)] for k in range(args.warmup)])
     note("warm-up done")
-    stages = []
+    stages, kept = [], []
     barrier()
     t0 = time.perf_counter()
-    run(args.steps, stages)
-    # final result gather: per-frame segment counts and padded segment lists of the last batch to rank 0
-    seg, cnt = results[(args.steps - 1) % args.slots]
-    note("timed steps done")
-    gathered = shard.gather_segments(seg, cnt, dst=0, device=coll_device if use_dist else None)
+    run(jobs, stages, kept)
+    note("timed batches done")
+    # the final result gather, the path's only exchange between ranks: every frame's segments of every clip, unpadded
+    rows = np.concatenate([r for r, _ in kept]) if kept else np.zeros((0, 4), np.int32)
+    counts = np.concatenate([c for _, c in kept]) if kept else np.zeros(0, np.int32)
+    gathered = shard.gather_compact(rows, counts, dst=0, device=coll_device if use_dist else None)
     note("gathered")
     barrier()
     dt = time.perf_counter() - t0
@@ -228,7 +261,18 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    fps = world * args.steps * batch / dt
+    nclips_total = args.clips if args.clips > 0 else world
+    total_frames = nclips_total * frames_per_clip
+    fps = total_frames / dt
+    timed_steps = len(jobs)
+    if rank == 0:
+        # what arrived must be every frame of every clip, in each rank's own clip order
+        got_frames = sum(len(c) for _, c in gathered)
+        got_clips = sum(len(shard.clip_assignment(args.clips, world, r)) if args.clips > 0 else 1 for r in range(len(gathered)))
+        if got_frames != total_frames or got_clips != nclips_total or any(len(r) != int(c.sum()) for r, c in gathered):
+            sys.exit("final gather is incomplete: %d frames of %d clips arrived, %d of %d expected"
+                     % (got_frames, got_clips, total_frames, nclips_total))
+    seg, cnt = results[(timed_steps - 1) % args.slots] if jobs else (None, np.zeros(1, np.int32))
 
     out = None
     if rank == 0:
@@ -240,14 +284,21 @@ def main():
         stage_bytes = 4.0 * W * H * batch
         out = {
             "metric": "1080p lane-pipeline frames/sec", "value": round(fps, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": args.steps if args.clips == 0 else timed_steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / max(timed_steps, 1) * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if args.clips == 0 else "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "synthetic 1080p road frames (BASELINE configs[2]), batch=%d per step, recipe north_star: "
-                                   "BGR2GRAY -> GaussianBlur 5x5 -> Canny(100,200) -> triangle ROI -> full-vote accumulator "
-                                   "-> HoughLinesP(6, pi/60, 160, 40, 25); inputs resident in HBM" % batch,
+            "config": {"workload": ("synthetic 1080p road frames (BASELINE configs[2]), one clip of %d frames per GPU" % frames_per_clip
+                                    if args.clips == 0 else
+                                    "%d synthetic 1080p clips x %d frames (BASELINE configs[4] with %d instead of 2,000 frames a clip), "
+                                    "clip c on GPU c mod %d" % (args.clips, frames_per_clip, frames_per_clip, world))
+                                   + ", batch=%d per step (two distinct batches of a clip alternating), recipe north_star: "
+                                     "BGR2GRAY -> GaussianBlur 5x5 -> Canny(100,200) -> triangle ROI -> full-vote accumulator "
+                                     "-> HoughLinesP(6, pi/60, 160, 40, 25); inputs resident in HBM; every frame's segments "
+                                     "gathered to rank 0 at the end" % batch,
                        "width": W, "height": H, "batch": batch, "slots_in_flight": args.slots,
-                       "sharding": "one clip per GPU, no data-path collective, final segment gather"},
+                       "sharding": "clip-major (clip c on GPU c mod N), no data-path collective, one final unpadded segment gather",
+                       "clips": nclips_total, "frames_per_clip": frames_per_clip},
             "roofline": {"bound": "hbm", "kernel": "k_front_stream<true, 0, false>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(batch),
@@ -258,7 +309,8 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in mean.items()},
             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default 4)"),
             "streams_sharing_a_queue": pipe.shared_queues(),
-            "segments_frame0": int(cnt[0]), "gathered_ranks": len(gathered), "hyst_closure_rounds_max_total": list(pipe.hyst_rounds(0)),
+            "segments_frame0": int(cnt[0]), "gathered_ranks": len(gathered), "gathered_frames": got_frames,
+            "gathered_segments": int(sum(len(r) for r, _ in gathered)), "hyst_closure_rounds_max_total": list(pipe.hyst_rounds(0)),
         }
 
         # exclusive timings: one batch in flight, nothing else on the GPU
@@ -284,11 +336,18 @@ def main():
         out["vote"] = vote_rates(ptr, batch, local_rank)
 
         if not args.no_streaming:
-            # PCIe-inclusive rate: pinned host ring -> hipMemcpyAsync -> pipeline, slots overlapped (never `value`)
+            # BASELINE configs[2] as written -- "streaming with pinned async upload": pinned host ring -> hipMemcpyAsync
+            # on the upload stream -> pipeline, slots overlapped.  PCIe-bound (6.2 MB per frame), so it carries its own
+            # roofline: the host-to-device rate of a plain pinned copy of one batch, measured here.  Never `value`.
             pinned = [pipe.pinned_frames(batch) for _ in range(args.slots)]
+            reps = (batch + len(frames) - 1) // len(frames)
             for p in pinned:
-                p[:] = frames
-            ssteps = max(args.slots * 2, 6)
+                p[:] = np.concatenate([frames] * reps)[:batch]
+            ssteps = max(args.slots * 3, 9)
+            for slot in range(args.slots):           # first touch of the upload stream outside the timed loop
+                pipe.submit(slot, pinned[slot])
+            for slot in range(args.slots):
+                pipe.wait(slot)
             t1 = time.perf_counter()
             inflight = []
             for k in range(ssteps):
@@ -299,10 +358,25 @@ def main():
                 inflight.append(slot)
             for s in inflight:
                 pipe.wait(s)
-            out["streaming_fps_pcie_inclusive"] = round(ssteps * batch / (time.perf_counter() - t1), 1)
+            sfps = ssteps * batch / (time.perf_counter() - t1)
+            src = torch.from_numpy(pinned[0].reshape(-1))           # the same pinned block, copied by torch alone
+            dst = torch.empty(src.numel(), dtype=torch.uint8, device="cuda")
+            best = 0.0
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                dst.copy_(src, non_blocking=True)
+                torch.cuda.synchronize()
+                best = max(best, src.numel() / (time.perf_counter() - t2) / 1e9)
+            out["streaming_fps_pcie_inclusive"] = round(sfps, 1)
+            out["streaming_roofline"] = {"bound": "pcie", "achieved": round(sfps * frame_bytes / 1e9, 2), "peak": round(best, 2),
+                                         "unit": "GB/s", "frac": round(sfps * frame_bytes / 1e9 / best, 4),
+                                         "note": "peak = host-to-device rate of one pinned %d-frame batch copied alone, measured "
+                                                 "in this run" % batch}
+            del dst
 
         if world == 1 and not args.no_cpu_baseline:
-            sample = frames[:min(batch, 128)]
+            sample = frames[:min(len(frames), 128)]
             v = cpu_baseline(sample, rec, pipe.roi, host_threads)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": host_threads, "kind": "port",
                                    "sample": "%d of the same 1080p frames through the same recipe with the scalar C oracle "

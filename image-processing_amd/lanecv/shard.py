@@ -38,6 +38,58 @@ def gather_segments(seg, cnt, dst=0, device=None):
     return [(s.cpu().numpy(), c.cpu().numpy()) for s, c in zip(seg_all, cnt_all)]
 
 
+def compact(seg, cnt):
+    """Padded (n, cap, 4) segments + (n,) counts -> the (sum(cnt), 4) rows of all frames back to back (frame order kept)."""
+    seg = np.asarray(seg)
+    cnt = np.asarray(cnt)
+    keep = np.arange(seg.shape[1], dtype=cnt.dtype)[None, :] < cnt[:, None]
+    return seg[keep]
+
+
+def gather_compact(rows, counts, dst=0, device=None):
+    """Final gather of a rank's whole result to rank `dst` without the padding: `rows` (k, 4) int32 are the segments
+    of all its frames back to back, `counts` (n,) int32 the segments per frame, in processing order (clip after clip).
+    Ranks may hold different n and k.  Returns on dst a list over ranks of (rows, counts), elsewhere None.
+    Three collectives in all -- the sizes, the counts, the rows -- whatever the number of frames."""
+    import torch
+    import torch.distributed as dist
+    rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [(rows, counts)]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else "cpu"
+    sizes = torch.tensor([len(counts), len(rows)], dtype=torch.int64, device=dev)
+    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [tuple(int(v) for v in t.cpu().tolist()) for t in all_sizes]
+    max_n = max(1, max(n for n, _ in all_sizes))
+    max_k = max(1, max(k for _, k in all_sizes))
+    ct = torch.zeros(max_n, dtype=torch.int32)
+    ct[:len(counts)] = torch.from_numpy(counts)
+    rt = torch.zeros((max_k, 4), dtype=torch.int32)
+    rt[:len(rows)] = torch.from_numpy(rows)
+    ct, rt = ct.to(dev), rt.to(dev)
+    c_all = [torch.empty_like(ct) for _ in range(world)] if rank == dst else None
+    r_all = [torch.empty_like(rt) for _ in range(world)] if rank == dst else None
+    dist.gather(ct, c_all, dst=dst)
+    dist.gather(rt, r_all, dst=dst)
+    if rank != dst:
+        return None
+    return [(r_all[r].cpu().numpy()[:k], c_all[r].cpu().numpy()[:n]) for r, (n, k) in enumerate(all_sizes)]
+
+
+def split_clips(rows, counts, clips, frames_per_clip):
+    """What one rank sent through gather_compact, cut back into its clips: {clip: list over frames of (k, 4) arrays}."""
+    out = {}
+    ends = np.cumsum(counts)
+    starts = ends - counts
+    for i, c in enumerate(clips):
+        fr = range(i * frames_per_clip, (i + 1) * frames_per_clip)
+        out[c] = [rows[starts[t]:ends[t]] for t in fr]
+    return out
+
+
 def unpad(seg, cnt):
     """Padded (n, cap, 4) + counts -> list of (k, 4) arrays, one per frame."""
     return [seg[i, :cnt[i]].copy() for i in range(len(cnt))]

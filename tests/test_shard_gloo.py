@@ -42,6 +42,18 @@ def _worker(rank, world, port, q):
         if rank == 0:
             for r, (s, n) in enumerate(got):
                 out[shard.clip_assignment(NCLIPS, world, r)[mine.index(c)]] = (s, n)
+    # the whole result in one unpadded gather, ranks holding different numbers of clips (3 clips over 2 ranks)
+    mine3 = shard.clip_assignment(3, world, rank)
+    rows, counts = [], []
+    for c in mine3:
+        seg, cnt = _clip_segments(c)
+        rows.append(shard.compact(seg, cnt))
+        counts.append(cnt)
+    got = shard.gather_compact(np.concatenate(rows), np.concatenate(counts), dst=0)
+    if rank == 0:
+        out["compact"] = {}
+        for r, (rr, cc) in enumerate(got):
+            out["compact"].update(shard.split_clips(rr, cc, shard.clip_assignment(3, world, r), NFRAMES))
     dist.barrier()
     if rank == 0:
         q.put(out)
@@ -67,6 +79,13 @@ def test_two_rank_gather_matches_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    comp = out.pop("compact")
+    assert sorted(comp) == [0, 1, 2]
+    for c in range(3):
+        seg, cnt = _clip_segments(c)
+        assert len(comp[c]) == NFRAMES
+        for t in range(NFRAMES):
+            assert np.array_equal(comp[c][t], seg[t, :cnt[t]])
     assert sorted(out) == list(range(NCLIPS))
     total = 0
     for c in range(NCLIPS):
