@@ -157,5 +157,14 @@ void launch_fill_spans(uint8_t *img, int W, int H, const PolyEdgeDev *edges, int
                        int color, hipStream_t st);
 void launch_draw_lines(uint8_t *img, int W, int H, const LineDev *lines, int nlines, int color, hipStream_t st);
 void launch_fill_rect(uint8_t *img, int W, int H, int x1, int y1, int x2, int y2, int color, hipStream_t st);
+// thick lines on dense images of cn channels (kernels_poly.hip); color = one byte per channel, channel 0 lowest
+struct TrapDev { int y0, y1; long long xa, dxa, xb, dxb; };              // rows [y0, y1) of FillConvexPoly's edge walk
+struct Line2Dev { int xmajor, ecount; long long major0, minor0, step, endx, endy; };   // Line2 after its set-up
+void launch_paint_traps(uint8_t *img, int W, int H, int cn, const TrapDev *traps, int ntraps, uint32_t color, hipStream_t st);
+void launch_paint_line2(uint8_t *img, int W, int H, int cn, const Line2Dev *lines, int nlines, int maxcount, uint32_t color,
+                        hipStream_t st);
+void launch_paint_circles(uint8_t *img, int W, int H, int cn, const int2 *centres, int ncircles, const int *hw, int radius,
+                          uint32_t color, hipStream_t st);
+void launch_draw_lines_cn(uint8_t *img, int W, int H, int cn, const LineDev *lines, int nlines, uint32_t color, hipStream_t st);
 
 }  // namespace lanecv

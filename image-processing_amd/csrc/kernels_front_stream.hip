@@ -94,25 +94,10 @@ __device__ __forceinline__ uint32_t add2k(uint32_t v, uint32_t k) {
     asm("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(v));
     return r;
 }
-__device__ __forceinline__ uint32_t ksub2(uint32_t k, uint32_t v) {
-    uint32_t r;
-    asm("v_sub_u32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(v));
-    return r;
-}
 __device__ __forceinline__ uint32_t sub2k(uint32_t v, uint32_t k) {
     uint32_t r;
     asm("v_subrev_u32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(v));
     return r;
-}
-__device__ __forceinline__ uint32_t pkmaxu(uint32_t a, uint32_t b) {
-    return R32(__builtin_elementwise_max(U2(a), U2(b)));
-}
-// packed u16 saturating a - b (0 where a <= b)
-__device__ __forceinline__ uint32_t satsub(uint32_t a, uint32_t b) {
-    return R32(__builtin_elementwise_sub_sat(U2(a), U2(b)));
-}
-__device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) {
-    return R32(__builtin_elementwise_min(U2(a), U2(b)));
 }
 // The next three are inline assembly so that the optimiser keeps them packed (it otherwise splits the
 // halves again into 16-bit compares and selects).  None of their results feeds a DPP move directly.

@@ -6,7 +6,7 @@ source-compatible for these calls:
 
     cvtColor (COLOR_BGR2GRAY / COLOR_RGB2GRAY / COLOR_BGR2HSV / COLOR_RGB2HSV),
     resize (INTER_LINEAR, explicit dsize), GaussianBlur ((5,5), sigma 0), Canny (aperture 3, L1), fillPoly (LINE_8, shift 0),
-    rectangle (filled), inRange (8UC3, integer bounds), bitwise_or, bitwise_and (optional mask),
+    rectangle (filled), line / polylines (LINE_8, any thickness), inRange (8UC3, integer bounds), bitwise_or, bitwise_and (optional mask),
     HoughLinesP, addWeighted
 
 Same positional/keyword signatures and return conventions as cv2 (fillPoly and
@@ -24,8 +24,8 @@ from . import _abi
 from ._abi import error
 from .glue import KalmanFilter   # host-side, as cv2.KalmanFilter is (`1000_Lane_Stabilizer.py:33`)
 
-__all__ = ["cvtColor", "resize", "GaussianBlur", "Canny", "fillPoly", "rectangle", "inRange", "bitwise_or", "bitwise_and",
-           "HoughLinesP", "addWeighted", "hough_accumulator", "KalmanFilter", "error"]
+__all__ = ["cvtColor", "resize", "GaussianBlur", "Canny", "fillPoly", "rectangle", "line", "polylines", "inRange", "bitwise_or",
+           "bitwise_and", "HoughLinesP", "addWeighted", "hough_accumulator", "KalmanFilter", "error"]
 
 COLOR_BGR2GRAY = 6
 COLOR_RGB2GRAY = 7
@@ -195,6 +195,67 @@ def rectangle(img, pt1, pt2, color, thickness=1, lineType=LINE_8, shift=0):
     h, w = img.shape
     _abi.check(_abi.lib().lc_rectangle_filled(_abi.context(), _abi.ptr(img), w, h, img.strides[0],
                                               int(pt1[0]), int(pt1[1]), int(pt2[0]), int(pt2[1]), _color(color)))
+    return img
+
+
+def _draw_target(img, name):
+    if not isinstance(img, _np.ndarray) or img.ndim not in (2, 3):
+        raise error("%s: img must be a 2- or 3-dimensional numpy array" % name)
+    img = _image(img, "img", img.ndim, writable=True)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    if cn > 4:
+        raise error("%s: at most 4 channels are supported, got %d" % (name, cn), _abi.LC_EUNSUPPORTED)
+    dense = img.strides[-1] == 1 and (img.ndim == 2 or img.strides[1] == cn) and img.strides[0] >= img.shape[1] * cn
+    if not dense:
+        raise error("%s: pixels of a row of an in-place target must be dense" % name, _abi.LC_EUNSUPPORTED)
+    return img, cn
+
+
+def _color_n(color, cn):
+    """cv2's Scalar: up to four numbers, missing ones 0; one value per channel, rounded and clamped."""
+    c = list(color) if isinstance(color, (tuple, list, _np.ndarray)) else [color]
+    c = [float(v) for v in c][:4] + [0.0] * 4
+    return (_C.c_int * 4)(*[int(min(255, max(0, _np.rint(v)))) for v in c[:4]])
+
+
+def _line_args(name, thickness, lineType, shift):
+    if lineType not in (LINE_8, 0) or shift != 0:
+        raise error("%s: only lineType=LINE_8 and shift=0 are supported" % name, _abi.LC_EUNSUPPORTED)
+    if int(thickness) != thickness or thickness < 1:
+        raise error("%s: thickness must be a positive integer, got %r" % (name, thickness))
+    return int(thickness)
+
+
+def line(img, pt1, pt2, color, thickness=1, lineType=LINE_8, shift=0):
+    """cv2.line on an 8-bit image of 1..4 channels, in place (LINE_8, shift 0); returns img.
+    Reference: Simple Lane Detection with OpenCV_2(images).py:47."""
+    img, cn = _draw_target(img, "line")
+    t = _line_args("line", thickness, lineType, shift)
+    h, w = img.shape[:2]
+    _abi.check(_abi.lib().lc_line(_abi.context(), _abi.ptr(img), w, h, img.strides[0], cn, int(pt1[0]), int(pt1[1]),
+                                  int(pt2[0]), int(pt2[1]), _color_n(color, cn), t))
+    return img
+
+
+def polylines(img, pts, isClosed, color, thickness=1, lineType=LINE_8, shift=0):
+    """cv2.polylines on an 8-bit image of 1..4 channels, in place; `pts` is a sequence (or 3-D array) of
+    polygons of integer vertices, (N, 2) or (N, 1, 2) each; returns img.
+    Reference: Simple Lane Detection with OpenCV_5(mp4).py:41, F1_vo_Lane_Tracking.py:138."""
+    img, cn = _draw_target(img, "polylines")
+    t = _line_args("polylines", thickness, lineType, shift)
+    polys = []
+    for p in pts:
+        p = _np.asarray(p)
+        if not _np.issubdtype(p.dtype, _np.integer):
+            raise error("polylines: polygon vertices must be integers (cv2 asserts CV_32S), got %s" % p.dtype)
+        if p.size and (p.ndim < 2 or p.shape[-1] != 2):
+            raise error("polylines: each polygon must be an (N, 2) or (N, 1, 2) array, got shape %s" % (p.shape,))
+        polys.append(_np.ascontiguousarray(p.reshape(-1, 2), dtype=_np.int32))
+    flat = _np.ascontiguousarray(_np.concatenate(polys, axis=0)) if polys else _np.zeros((0, 2), _np.int32)
+    npts = (_C.c_int * max(1, len(polys)))(*[len(p) for p in polys])
+    h, w = img.shape[:2]
+    _abi.check(_abi.lib().lc_polylines(_abi.context(), _abi.ptr(img), w, h, img.strides[0], cn, _abi.ptr(flat),
+                                       _C.cast(npts, _C.c_void_p), len(polys), int(bool(isClosed)), _color_n(color, cn), t))
     return img
 
 

@@ -26,7 +26,7 @@ STAGE_UPLOAD, STAGE_EDGE, STAGE_POINTS, STAGE_VOTE, STAGE_LINES, STAGE_TOTAL, ST
 # every symbol include/lanecv.h declares
 SYMBOLS = [
     "lc_version", "lc_last_error", "lc_create", "lc_destroy", "lc_host_alloc_pinned", "lc_host_free",
-    "lc_cvt_gray", "lc_cvt_hsv", "lc_in_range3", "lc_or", "lc_and3_mask", "lc_resize_linear", "lc_add_weighted", "lc_gaussian5", "lc_canny", "lc_canny_noalloc", "lc_fill_poly", "lc_rectangle_filled", "lc_and",
+    "lc_cvt_gray", "lc_cvt_hsv", "lc_in_range3", "lc_or", "lc_and3_mask", "lc_resize_linear", "lc_add_weighted", "lc_gaussian5", "lc_canny", "lc_canny_noalloc", "lc_fill_poly", "lc_rectangle_filled", "lc_line", "lc_polylines", "lc_and",
     "lc_hough_geometry", "lc_hough_accum", "lc_hough_lines_p", "lc_lds_atomic_rate",
     "lc_pipe_create", "lc_pipe_destroy", "lc_pipe_submit_host", "lc_pipe_submit_device", "lc_pipe_wait",
     "lc_pipe_read", "lc_pipe_read_points", "lc_pipe_stage_ms", "lc_pipe_input_device_ptr", "lc_pipe_upload", "lc_pipe_hyst_rounds", "lc_pipe_shared_queues",
@@ -75,6 +75,8 @@ def lib():
         L.lc_canny_noalloc.argtypes = [vp, vp, i, i, d, d, vp, vp]
         L.lc_fill_poly.argtypes = [vp, vp, i, i, sz, vp, vp, i, i]
         L.lc_rectangle_filled.argtypes = [vp, vp, i, i, sz, i, i, i, i, i]
+        L.lc_line.argtypes = [vp, vp, i, i, sz, i, i, i, i, i, C.POINTER(i), i]
+        L.lc_polylines.argtypes = [vp, vp, i, i, sz, i, vp, vp, i, i, C.POINTER(i), i]
         L.lc_and.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, i, i]
         L.lc_hough_geometry.argtypes = [i, i, d, d, C.POINTER(i), C.POINTER(i)]
         L.lc_hough_accum.argtypes = [vp, vp, i, i, sz, d, d, vp, i, C.POINTER(i), C.POINTER(i)]

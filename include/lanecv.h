@@ -132,6 +132,19 @@ int lc_fill_poly(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride,
 int lc_rectangle_filled(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride,
                         int x1, int y1, int x2, int y2, int color);
 
+/* cv2.line(img, pt1, pt2, color, thickness) with LINE_8, shift 0, on an 8-bit image of 1..4 channels, in place.
+ * color holds one value per channel (clamped to 0..255).  thickness 1 is the 8-connected line; above it
+ * OpenCV's thick line: the convex quad around the segment, filled and outlined, with round caps at both ends.
+ * Replaces: Simple Lane Detection with OpenCV_2(images).py:47 (drawn with thickness 5 from :146). */
+int lc_line(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride, int channels, int x1, int y1, int x2, int y2,
+            const int *color, int thickness);
+
+/* cv2.polylines(img, pts, isClosed, color, thickness): every edge of every contour as a thick line with a round
+ * cap at its far end (an open polyline caps its first point too).  pts / npts as in lc_fill_poly.
+ * Replaces: Simple Lane Detection with OpenCV_5(mp4).py:41, :48 (thickness 8), F1_vo_Lane_Tracking.py:138, :140 (5). */
+int lc_polylines(lc_ctx *ctx, uint8_t *img, int w, int h, size_t stride, int channels, const int32_t *pts, const int *npts,
+                 int ncontours, int is_closed, const int *color, int thickness);
+
 /* cv2.bitwise_and(a, b[, mask=mask]) on 8UC1 images; mask may be NULL.
  * Replaces: Simple Lane Detection with OpenCV_2(images).py:23,
  *           F1_vo_Lane_Tracking.py:102 (mask=), :112. */

@@ -513,6 +513,284 @@ int lo_rectangle_filled(uint8_t *img, int w, int h, long stride,
 }
 
 /* ------------------------------------------------------------------ */
+/* drawing.cpp: line / polylines with a thickness (ThickLine, Line2,    */
+/* FillConvexPoly, Circle) on 8-bit images of cn channels, LINE_8,      */
+/* shift 0.  Reference call sites: Simple Lane Detection with           */
+/* OpenCV_2(images).py:27-51 (cv2.line, thickness 5 as called at :146), */
+/* ..._5(mp4).py:21-52 and F1_vo_Lane_Tracking.py:137-140               */
+/* (cv2.polylines, thickness 8 / 5).                                    */
+/* Restated from memory of OpenCV 4.5+, NOT checked against a cv2       */
+/* (parity unpinned).  By this code a thick line is the convex quad     */
+/* p +- dp with |dp| = thickness / 2 (+ 1/2 for odd thicknesses), filled */
+/* AND outlined, plus a filled circle of radius (thickness + 1) / 2     */
+/* (truncated) at the ends that have a cap: a horizontal line of        */
+/* thickness 5 covers 7 rows, thickness 8 covers 9 rows.                */
+/* ------------------------------------------------------------------ */
+static void put_px(uint8_t *img, int w, int h, long stride, int cn, int64_t x, int64_t y, const uint8_t *col)
+{
+    if (x >= 0 && x < w && y >= 0 && y < h) memcpy(img + y * stride + x * cn, col, (size_t)cn);
+}
+
+/* ICV_HLINE: x1 .. x2 inclusive, already inside the image */
+static void hline_cn(uint8_t *img, long stride, int cn, int y, int x1, int x2, const uint8_t *col)
+{
+    for (int x = x1; x <= x2; x++) memcpy(img + (long)y * stride + (long)x * cn, col, (size_t)cn);
+}
+
+/* Line(img, pt1, pt2, color, 8) for any channel count (the thin case of ThickLine) */
+static void draw_line8_cn(uint8_t *img, int w, int h, long stride, int cn, pt64 a, pt64 b, const uint8_t *col)
+{
+    if ((uint64_t)a.x >= (uint64_t)w || (uint64_t)b.x >= (uint64_t)w ||
+        (uint64_t)a.y >= (uint64_t)h || (uint64_t)b.y >= (uint64_t)h) {
+        if (!clip_line(w, h, &a, &b)) return;
+    }
+    int delta_x = 1, delta_y = 1;
+    int dx = (int)(b.x - a.x), dy = (int)(b.y - a.y);
+    if (dx < 0) { dx = -dx; dy = -dy; a = b; }
+    if (dy < 0) { dy = -dy; delta_y = -1; }
+    int vert = dy > dx;
+    if (vert) { int t = dx; dx = dy; dy = t; t = delta_x; delta_x = delta_y; delta_y = t; }
+    int err = dx - (dy + dy);
+    const int plus_delta = dx + dx, minus_delta = -(dy + dy);
+    int count = dx + 1;
+    int px = (int)a.x, py = (int)a.y;
+    for (int i = 0; i < count; i++) {
+        memcpy(img + (long)py * stride + (long)px * cn, col, (size_t)cn);
+        int neg = err < 0;
+        err += minus_delta + (neg ? plus_delta : 0);
+        if (!vert) { px += delta_x; if (neg) py += delta_y; }
+        else       { py += delta_x; if (neg) px += delta_y; }
+    }
+}
+
+/* Line2: a line between 16.16 fixed-point end points, one pixel per step of the major axis */
+static void line2(uint8_t *img, int w, int h, long stride, int cn, pt64 pt1, pt64 pt2, const uint8_t *col)
+{
+    if (!clip_line((int64_t)w << XY_SHIFT, (int64_t)h << XY_SHIFT, &pt1, &pt2)) return;
+    int64_t dx = pt2.x - pt1.x, dy = pt2.y - pt1.y;
+    const int64_t j = dx < 0 ? -1 : 0, ax = (dx ^ j) - j;
+    const int64_t i = dy < 0 ? -1 : 0, ay = (dy ^ i) - i;
+    int64_t x_step, y_step;
+    int ecount;
+    if (ax > ay) {
+        dy = (dy ^ j) - j;
+        if (j) { pt64 t = pt1; pt1 = pt2; pt2 = t; }
+        x_step = XY_ONE;
+        y_step = dy * (1 << XY_SHIFT) / (ax | 1);
+        ecount = (int)((pt2.x - pt1.x) >> XY_SHIFT);
+    } else {
+        dx = (dx ^ i) - i;
+        if (i) { pt64 t = pt1; pt1 = pt2; pt2 = t; }
+        x_step = dx * (1 << XY_SHIFT) / (ay | 1);
+        y_step = XY_ONE;
+        ecount = (int)((pt2.y - pt1.y) >> XY_SHIFT);
+    }
+    pt1.x += XY_ONE >> 1;
+    pt1.y += XY_ONE >> 1;
+    put_px(img, w, h, stride, cn, (pt2.x + (XY_ONE >> 1)) >> XY_SHIFT, (pt2.y + (XY_ONE >> 1)) >> XY_SHIFT, col);
+    if (ax > ay) {
+        pt1.x >>= XY_SHIFT;
+        while (ecount >= 0) {
+            put_px(img, w, h, stride, cn, pt1.x, pt1.y >> XY_SHIFT, col);
+            pt1.x++;
+            pt1.y += y_step;
+            ecount--;
+        }
+    } else {
+        pt1.y >>= XY_SHIFT;
+        while (ecount >= 0) {
+            put_px(img, w, h, stride, cn, pt1.x >> XY_SHIFT, pt1.y, col);
+            pt1.x += x_step;
+            pt1.y++;
+            ecount--;
+        }
+    }
+    (void)x_step; (void)y_step;
+}
+
+/* FillConvexPoly(img, v, npts, color, LINE_8, shift = XY_SHIFT): outline by Line2, then two edge chains walked
+ * down from the top vertex, one span per row */
+static void fill_convex_poly16(uint8_t *img, int w, int h, long stride, int cn, const pt64 *v, int npts, const uint8_t *col)
+{
+    struct { int idx, di; int64_t x, dx; int ye; } edge[2];
+    const int shift = XY_SHIFT;
+    const int64_t delta = 1 << shift >> 1;
+    int i, y, imin = 0;
+    int edges = npts;
+    int64_t xmin, xmax, ymin, ymax;
+    const int delta1 = XY_ONE >> 1, delta2 = XY_ONE >> 1;
+    pt64 p0 = v[npts - 1];
+    xmin = xmax = v[0].x;
+    ymin = ymax = v[0].y;
+    for (i = 0; i < npts; i++) {
+        pt64 p = v[i];
+        if (p.y < ymin) { ymin = p.y; imin = i; }
+        if (p.y > ymax) ymax = p.y;
+        if (p.x > xmax) xmax = p.x;
+        if (p.x < xmin) xmin = p.x;
+        line2(img, w, h, stride, cn, p0, p, col);
+        p0 = p;
+    }
+    xmin = (xmin + delta) >> shift;
+    xmax = (xmax + delta) >> shift;
+    ymin = (ymin + delta) >> shift;
+    ymax = (ymax + delta) >> shift;
+    if (npts < 3 || (int)xmax < 0 || (int)ymax < 0 || (int)xmin >= w || (int)ymin >= h) return;
+    if (ymax > h - 1) ymax = h - 1;
+    edge[0].idx = edge[1].idx = imin;
+    edge[0].ye = edge[1].ye = y = (int)ymin;
+    edge[0].di = 1;
+    edge[1].di = npts - 1;
+    edge[0].x = edge[1].x = -XY_ONE;
+    edge[0].dx = edge[1].dx = 0;
+    do {
+        for (i = 0; i < 2; i++) {
+            if (y >= edge[i].ye) {
+                int idx0 = edge[i].idx, di = edge[i].di;
+                int idx = idx0 + di;
+                if (idx >= npts) idx -= npts;
+                int ty = 0;
+                for (; edges-- > 0;) {
+                    ty = (int)((v[idx].y + delta) >> shift);
+                    if (ty > y) {
+                        const int64_t xs = v[idx0].x, xe = v[idx].x;
+                        edge[i].ye = ty;
+                        edge[i].dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        edge[i].x = xs;
+                        edge[i].idx = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += di;
+                    if (idx >= npts) idx -= npts;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            int left = 0, right = 1;
+            if (edge[0].x > edge[1].x) { left = 1; right = 0; }
+            int xx1 = (int)((edge[left].x + delta1) >> XY_SHIFT);
+            int xx2 = (int)((edge[right].x + delta2) >> XY_SHIFT);
+            if (xx2 >= 0 && xx1 < w) {
+                if (xx1 < 0) xx1 = 0;
+                if (xx2 >= w) xx2 = w - 1;
+                hline_cn(img, stride, cn, y, xx1, xx2, col);
+            }
+        }
+        edge[0].x += edge[0].dx;
+        edge[1].x += edge[1].dx;
+    } while (++y <= (int)ymax);
+}
+
+/* Circle(img, center, radius, color, fill = 1): the midpoint circle, every step four horizontal spans */
+static void circle_filled(uint8_t *img, int w, int h, long stride, int cn, int cx, int cy, int radius, const uint8_t *col)
+{
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        int mask;
+        int y11 = cy - dy, y12 = cy + dy, y21 = cy - dx, y22 = cy + dx;
+        int x11 = cx - dx, x12 = cx + dx, x21 = cx - dy, x22 = cx + dy;
+        if (x11 < w && x12 >= 0 && y21 < h && y22 >= 0) {
+            if (x11 < 0) x11 = 0;
+            if (x12 > w - 1) x12 = w - 1;
+            if ((unsigned)y11 < (unsigned)h) hline_cn(img, stride, cn, y11, x11, x12, col);
+            if ((unsigned)y12 < (unsigned)h) hline_cn(img, stride, cn, y12, x11, x12, col);
+            if (x21 < w && x22 >= 0) {
+                if (x21 < 0) x21 = 0;
+                if (x22 > w - 1) x22 = w - 1;
+                if ((unsigned)y21 < (unsigned)h) hline_cn(img, stride, cn, y21, x21, x22, col);
+                if ((unsigned)y22 < (unsigned)h) hline_cn(img, stride, cn, y22, x21, x22, col);
+            }
+        }
+        dy++;
+        err += plus;
+        plus += 2;
+        mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+/* ThickLine(img, p0, p1, color, thickness, LINE_8, flags, shift = 0): flags bit 0 / 1 = round cap at p0 / p1 */
+static void thick_line(uint8_t *img, int w, int h, long stride, int cn, pt64 p0, pt64 p1, const uint8_t *col,
+                       int thickness, int flags)
+{
+    p0.x <<= XY_SHIFT; p0.y <<= XY_SHIFT; p1.x <<= XY_SHIFT; p1.y <<= XY_SHIFT;
+    if (thickness <= 1) {
+        pt64 a = {(p0.x + (XY_ONE >> 1)) >> XY_SHIFT, (p0.y + (XY_ONE >> 1)) >> XY_SHIFT};
+        pt64 b = {(p1.x + (XY_ONE >> 1)) >> XY_SHIFT, (p1.y + (XY_ONE >> 1)) >> XY_SHIFT};
+        draw_line8_cn(img, w, h, stride, cn, a, b, col);
+        return;
+    }
+    const double INV_XY_ONE = 1. / XY_ONE;
+    pt64 pt[4], dp = {0, 0};
+    const double dx = (double)(p0.x - p1.x) * INV_XY_ONE, dy = (double)(p1.y - p0.y) * INV_XY_ONE;
+    double r = dx * dx + dy * dy;
+    const int odd = thickness & 1;
+    thickness <<= XY_SHIFT - 1;
+    if (fabs(r) > 2.220446049250313e-16) {
+        r = (thickness + odd * XY_ONE * 0.5) / sqrt(r);
+        dp.x = cv_round_d(dy * r);
+        dp.y = cv_round_d(dx * r);
+        pt[0].x = p0.x + dp.x; pt[0].y = p0.y + dp.y;
+        pt[1].x = p0.x - dp.x; pt[1].y = p0.y - dp.y;
+        pt[2].x = p1.x - dp.x; pt[2].y = p1.y - dp.y;
+        pt[3].x = p1.x + dp.x; pt[3].y = p1.y + dp.y;
+        fill_convex_poly16(img, w, h, stride, cn, pt, 4, col);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (flags & (i + 1)) {
+            const int cx = (int)((p0.x + (XY_ONE >> 1)) >> XY_SHIFT), cy = (int)((p0.y + (XY_ONE >> 1)) >> XY_SHIFT);
+            circle_filled(img, w, h, stride, cn, cx, cy, (thickness + (XY_ONE >> 1)) >> XY_SHIFT, col);
+        }
+        p0 = p1;
+    }
+}
+
+static int color_bytes(const int *color, int cn, uint8_t *col)
+{
+    if (!color || cn < 1 || cn > 4) return LO_EINVAL;
+    for (int k = 0; k < cn; k++) col[k] = (uint8_t)(color[k] < 0 ? 0 : (color[k] > 255 ? 255 : color[k]));
+    return LO_OK;
+}
+
+/* cv2.line(img, pt1, pt2, color, thickness) */
+int lo_line(uint8_t *img, int w, int h, long stride, int cn, int x1, int y1, int x2, int y2, const int *color, int thickness)
+{
+    uint8_t col[4];
+    if (!img || w <= 0 || h <= 0 || thickness < 1 || color_bytes(color, cn, col)) return LO_EINVAL;
+    pt64 a = {x1, y1}, b = {x2, y2};
+    thick_line(img, w, h, stride, cn, a, b, col, thickness, 3);
+    return LO_OK;
+}
+
+/* cv2.polylines(img, pts, isClosed, color, thickness): PolyLine per contour */
+int lo_polylines(uint8_t *img, int w, int h, long stride, int cn, const int32_t *pts, const int *npts, int ncontours,
+                 int is_closed, const int *color, int thickness)
+{
+    uint8_t col[4];
+    if (!img || w <= 0 || h <= 0 || thickness < 1 || ncontours < 0 || (ncontours && (!pts || !npts)) || color_bytes(color, cn, col))
+        return LO_EINVAL;
+    const int32_t *v = pts;
+    for (int c = 0; c < ncontours; v += 2 * npts[c], c++) {
+        const int count = npts[c];
+        if (count <= 0) continue;
+        int i = is_closed ? count - 1 : 0;
+        int flags = 2 + !is_closed;
+        pt64 p0 = {v[2 * i], v[2 * i + 1]};
+        for (i = !is_closed; i < count; i++) {
+            pt64 p = {v[2 * i], v[2 * i + 1]};
+            thick_line(img, w, h, stride, cn, p0, p, col, thickness, flags);
+            p0 = p;
+            flags = 2;
+        }
+    }
+    return LO_OK;
+}
+
+/* ------------------------------------------------------------------ */
 /* hough.cpp: HoughLinesProbabilistic and its trig table.              */
 /* ------------------------------------------------------------------ */
 static int compute_numangle(double min_theta, double max_theta, double theta_step)

@@ -200,6 +200,38 @@ def rectangle_filled(img, pt1, pt2, color):
     return img
 
 
+def _draw_target(img):
+    assert img.dtype == np.uint8 and img.ndim in (2, 3) and img.flags.c_contiguous
+    h, w = img.shape[:2]
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    return h, w, cn
+
+
+def _color(color, cn):
+    c = list(color) if isinstance(color, (tuple, list, np.ndarray)) else [color]
+    c = (c + [0, 0, 0, 0])[:max(cn, 1)]
+    return (C.c_int * 4)(*([int(v) for v in c] + [0] * (4 - len(c))))
+
+
+def line(img, pt1, pt2, color, thickness=1):
+    """In place, like cv2.line (LINE_8, shift 0) on an 8-bit image of 1..4 channels."""
+    h, w, cn = _draw_target(img)
+    _chk(lib().lo_line(img.ctypes.data_as(C.c_void_p), w, h, C.c_long(w * cn), cn, int(pt1[0]), int(pt1[1]), int(pt2[0]),
+                       int(pt2[1]), _color(color, cn), int(thickness)), "line")
+    return img
+
+
+def polylines(img, pts, is_closed, color, thickness=1):
+    """In place, like cv2.polylines.  pts: list of (N,2) / (N,1,2) integer arrays."""
+    h, w, cn = _draw_target(img)
+    cs = [np.ascontiguousarray(np.asarray(c).reshape(-1, 2), dtype=np.int32) for c in pts]
+    npts = (C.c_int * max(1, len(cs)))(*[len(c) for c in cs])
+    flat = np.ascontiguousarray(np.concatenate(cs, axis=0) if cs else np.zeros((0, 2), np.int32))
+    _chk(lib().lo_polylines(img.ctypes.data_as(C.c_void_p), w, h, C.c_long(w * cn), cn, flat.ctypes.data_as(C.c_void_p), npts,
+                            len(cs), int(bool(is_closed)), _color(color, cn), int(thickness)), "polylines")
+    return img
+
+
 def hough_geometry(w, h, rho, theta):
     na, nr = C.c_int(), C.c_int()
     _chk(lib().lo_hough_geometry(w, h, C.c_double(rho), C.c_double(theta), C.byref(na), C.byref(nr), None, 0), "geometry")

@@ -301,3 +301,100 @@ def resize_linear_np(img, dsize):
     h0, h1 = h[r0], h[r1]
     out = (((b0[:, None, None] * (h0 >> 4)) >> 16) + ((b1[:, None, None] * (h1 >> 4)) >> 16) + 2) >> 2
     return out.astype(np.uint8).reshape((dh, dw) + a.shape[2:])
+
+
+# ---- thick lines (cv2.line / cv2.polylines with a thickness): an independent evaluation ---------------------------
+# Structured differently from the oracle's scan loops: a pixel set per primitive from closed forms, united at the end.
+def _circle_rows(radius):
+    """{dy: half width} of OpenCV's filled midpoint circle (each step paints rows +-dy with half width dx and rows
+    +-dx with half width dy)."""
+    rows = {}
+    err, dx, dy, plus, minus = 0, radius, 0, 1, 2 * radius - 1
+    while dx >= dy:
+        for r, hw in ((dy, dx), (-dy, dx), (dx, dy), (-dx, dy)):
+            rows[r] = max(rows.get(r, -1), hw)
+        dy += 1
+        err += plus
+        plus += 2
+        if err > 0:
+            err -= minus
+            dx -= 1
+            minus -= 2
+    return rows
+
+
+def _line2_pixels(w, h, p, q):
+    """Pixels of a line between 16.16 fixed-point points, for lines that need no clipping (both ends inside)."""
+    (x1, y1), (x2, y2) = p, q
+    assert 0 <= x1 < (w << 16) and 0 <= x2 < (w << 16) and 0 <= y1 < (h << 16) and 0 <= y2 < (h << 16)
+    out = {((x2 + 32768) >> 16, (y2 + 32768) >> 16)}
+    ax, ay = abs(x2 - x1), abs(y2 - y1)
+    tdiv = lambda a, b: abs(a) // b * (1 if a >= 0 else -1)            # C division truncates toward zero
+    if ax > ay:
+        if x2 < x1:
+            x1, y1, x2, y2 = x2, y2, x1, y1
+        step = tdiv((y2 - y1) * 65536, ax | 1)
+        for i in range(((x2 - x1) >> 16) + 1):
+            out.add((((x1 + 32768) >> 16) + i, (y1 + 32768 + i * step) >> 16))
+    else:
+        if y2 < y1:
+            x1, y1, x2, y2 = x2, y2, x1, y1
+        step = tdiv((x2 - x1) * 65536, ay | 1)
+        for i in range(((y2 - y1) >> 16) + 1):
+            out.add(((x1 + 32768 + i * step) >> 16, ((y1 + 32768) >> 16) + i))
+    return out
+
+
+def thick_line_pixels(w, h, p0, p1, thickness, caps=3):
+    """Set of (x, y) a thick line paints, for lines whose quad lies inside the image with a margin (no clipping):
+    outline of the quad p +- dp, rows between its corners filled between the two chains, round caps."""
+    assert thickness >= 2
+    X0, Y0, X1, Y1 = p0[0] << 16, p0[1] << 16, p1[0] << 16, p1[1] << 16
+    t15 = thickness << 15
+    pix = set()
+    dx, dy = (X0 - X1) / 65536.0, (Y1 - Y0) / 65536.0
+    rr = dx * dx + dy * dy
+    if rr > 2.220446049250313e-16:
+        r = (t15 + (thickness & 1) * 32768.0) / np.sqrt(rr)
+        dpx, dpy = int(np.rint(dy * r)), int(np.rint(dx * r))
+        quad = [(X0 + dpx, Y0 + dpy), (X0 - dpx, Y0 - dpy), (X1 - dpx, Y1 - dpy), (X1 + dpx, Y1 + dpy)]
+        for k in range(4):
+            pix |= _line2_pixels(w, h, quad[k - 1], quad[k])
+        # fill: the chain to the right and to the left of the topmost vertex (first of the lowest y), each edge walked
+        # from the rounded row of its upper end with slope ((xe - xs) * 2 + n) / (2 n), n = rows the edge spans
+        rows_of = [(y + 32768) >> 16 for _, y in quad]
+        imin = min(range(4), key=lambda k: (quad[k][1], k))
+        ymin, ymax = rows_of[imin], max(rows_of)
+
+        def chain(di):
+            xs_at = {}
+            idx0, y = imin, ymin
+            for _ in range(4):
+                idx = (idx0 + di) % 4
+                ty = rows_of[idx]
+                if ty > y:
+                    xs, xe = quad[idx0][0], quad[idx][0]
+                    num, den = (xe - xs) * 2 + (ty - y), 2 * (ty - y)
+                    slope = abs(num) // den * (1 if num >= 0 else -1)
+                    for yy in range(y, ty):
+                        xs_at[yy] = xs + (yy - y) * slope
+                    y = ty
+                idx0 = idx
+                if idx == imin:
+                    break
+            return xs_at
+
+        a, b = chain(1), chain(3)
+        for yy in range(ymin, ymax):
+            if yy in a and yy in b:
+                lo, hi = min(a[yy], b[yy]), max(a[yy], b[yy])
+                for xx in range((lo + 32768) >> 16, ((hi + 32768) >> 16) + 1):
+                    pix.add((xx, yy))
+    radius = (t15 + 32768) >> 16
+    rows = _circle_rows(radius)
+    for k, (cx, cy) in enumerate(((p0[0], p0[1]), (p1[0], p1[1]))):
+        if caps & (k + 1):
+            for r, hw in rows.items():
+                for xx in range(cx - hw, cx + hw + 1):
+                    pix.add((xx, cy + r))
+    return {(x, y) for x, y in pix if 0 <= x < w and 0 <= y < h}
