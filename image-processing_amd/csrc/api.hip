@@ -1098,6 +1098,12 @@ struct lc_pipe {
     bool resizes = false, resize_area2 = false, resize_dec3 = false;
     int src_w = 0, src_h = 0;
     size_t src_frame_bytes = 0;   // bytes of one submitted frame
+    // the reduction by exactly three is read by the front kernel itself (no resized frame exists then): without
+    // intermediates, without the colour gate, widths the streaming kernel takes
+    bool fused_dec3() const {
+        return resizes && resize_dec3 && !p.keep_intermediates && !has_gate && front_stream_supported(g) && !getenv("LANECV_FRONT_TILED") &&
+               !getenv("LANECV_NO_FUSED_RESIZE");
+    }
     DevBuf<int> resize_tab;
     // A pipeline owns three or four streams of equal priority (more HoughLinesP streams for small batches, below),
     // whatever its number of slots; a slot is a set of buffers and events.  HIP maps streams onto a few hardware
@@ -1222,14 +1228,16 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
         HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], es));
     }
     HIP_TRY(hipEventRecord(s.ev[EV_ESTART], es));
-    if (pp->resizes) {
+    // the exact reduction by three needs no pass of its own: the front kernel reads the source pixels it keeps
+    const bool fused_resize = pp->fused_dec3();
+    if (pp->resizes && !fused_resize) {
         launch_resize_linear(s.input, pp->src_w, pp->src_h, 3, n, w.bgr.p, w.g.W, w.g.H, pp->resize_tab.p, pp->resize_area2, es, pp->resize_dec3);
         s.input = w.bgr.p;
         s.input_bytes = (size_t)n * 3 * w.npix;
     }
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
-                 pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p);
+                 pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
     hipStream_t ps = pp->st_post;
@@ -1598,7 +1606,11 @@ int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes
             need = sizeof(int32_t) * (size_t)s->nframes * w.hg.numangle * w.hg.numrho; break;
         case LC_BUF_NPOINTS: src = (pipe->p.want_accumulator || pipe->p.want_segments || pipe->p.want_points) ? w.npoints.p : nullptr;
             need = sizeof(int) * s->nframes; break;
-        case LC_BUF_RESIZED: src = pipe->resizes ? w.bgr.p : nullptr; need = 3 * img; break;
+        case LC_BUF_RESIZED:
+            if (pipe->fused_dec3())
+                return fail(LC_EINVAL, "the resized frames are not materialised when the reduction by three is fused into the edge "
+                            "kernel; configure keep_intermediates to read them");
+            src = pipe->resizes ? w.bgr.p : nullptr; need = 3 * img; break;
         default: return fail(LC_EINVAL, "unknown buffer id %d", what);
     }
     if (!src) return fail(LC_EINVAL, "buffer %d is not produced by this pipeline's configuration", what);

@@ -80,7 +80,10 @@ int front_stream_strips(Geo g);     // 248-column strips per frame row
 // gate (may be null): the colour gate applied to the frame before the gray conversion; tab as above
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
-                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags = nullptr);
+                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags = nullptr,
+                         bool dec3 = false);
+// dec3: src holds frames of 3 W x 3 H pixels; the kernel takes source pixel (3x + 1, 3y + 1) for pixel (x, y), which is
+// what cv2.resize's bilinear reduction by exactly three yields (no gate, no intermediate images in this form)
 void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st);
 // in_kind: 0 = gray bytes in, 1 = interleaved 3-channel bytes in
 // gate (may be null, 3-channel input only): colour gate in front of the gray conversion.  Frames the
@@ -94,7 +97,7 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
                   int low, int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake,
                   uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
                   const GateDev *gate = nullptr, const int *tab = nullptr, uint8_t *gate_gray = nullptr,
-                  uint8_t *rowflags = nullptr);
+                  uint8_t *rowflags = nullptr, bool dec3 = false);
 // hysteresis to the fixed point: one workgroup per frame floods the tiles flagged in wake (by the front
 // kernel: those with weak pixels), then repeats over the tiles whose neighbours gained a strong border pixel
 // until a round flags none; rounds[f] receives the rounds frame f needed.  wake holds two arrays of

@@ -587,12 +587,12 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes, int low,
                   int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
-                  hipStream_t st, const GateDev *gate, const int *tab, uint8_t *gate_gray, uint8_t *rowflags) {
+                  hipStream_t st, const GateDev *gate, const int *tab, uint8_t *gate_gray, uint8_t *rowflags, bool dec3) {
     static const char *force_tiled = getenv("LANECV_FRONT_TILED");       // diagnostics: use the tiled kernel everywhere
     static const char *rows_env = getenv("LANECV_FRONT_ROWS");           // tuning: rows per streaming unit
     if (in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1')) {
         launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, wake, gray_out, blur_out,
-                            rows_env ? atoi(rows_env) : 0, gate, tab, st, rowflags);
+                            rows_env ? atoi(rows_env) : 0, gate, tab, st, rowflags, dec3);
         return;
     }
     if (gate && in_kind == 1) {   // gated gray first, then the tiled kernel on that gray image

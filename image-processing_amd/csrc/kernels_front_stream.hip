@@ -169,7 +169,10 @@ template <int P> using Phase = std::integral_constant<int, P>;
 //   HB  the strip holds a lane left of column 0 or right of column W - 1 (first and last strip of a frame row)
 //   FE  the unit touches the top or bottom of the frame: rows to load may lie outside it, Sobel rows replicate,
 //       magnitude rows outside the image are zero
-template <bool BLUR, int GATE, bool INTER, bool HB, bool FE>   // GATE: 0 none, 1 the colour gate
+//   DEC3  the frames arrive three times as wide and as high and are reduced by three first, as cv2.resize's bilinear
+//       interpolation does it: every sample point falls on a source pixel with the whole weight, so pixel (x, y) IS
+//       source pixel (3x + 1, 3y + 1).  The lane reads its four pixels out of 36 source bytes of every third row.
+template <bool BLUR, int GATE, bool INTER, bool HB, bool FE, bool DEC3 = false>   // GATE: 0 none, 1 the colour gate
 __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, const int s, const int y0, const int y1) {
     const int *__restrict__ gtab = a.gate_tab;
     const int lane = threadIdx.x & 63;
@@ -181,10 +184,14 @@ __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, cons
     const int jW = (W - X0) >> 2;                  // the lane that starts at column W
     const bool rb = lane == jW;
     constexpr bool has_border = HB;
-    const uint8_t *fsrc = a.src + (size_t)f * 3 * W * H;
+    static_assert(!DEC3 || GATE == 0, "the colour gate is not combined with the fused reduction");
+    constexpr int RS = DEC3 ? 3 : 1;               // source pixels per pixel, each way
+    constexpr int NL = DEC3 ? 6 : 3;               // dwords a lane keeps of a source row
+    const size_t frame_bytes = (size_t)3 * (RS * W) * (RS * H);
+    const uint8_t *fsrc = a.src + (size_t)f * frame_bytes;
     // lanes outside the image load a valid pixel group instead of nothing: what they hold never reaches
     // an output (border lanes are rewritten below, magnitudes outside the image are forced to zero)
-    const uint32_t lane_off = 3u * (uint32_t)min(max(px, 0), W - 4);
+    const uint32_t lane_off = (uint32_t)(3 * RS) * (uint32_t)min(max(px, 0), W - 4);
     constexpr int DB = BLUR ? 2 : 0;               // rows the blur delays the pipeline by
     constexpr uint32_t M8 = 0x00FF00FFu;
     // this lane's byte of the two bit planes (odd lanes 1..61 store: their nibble and the next lane's)
@@ -207,16 +214,26 @@ __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, cons
     Pair Mw[3] = {};
     Pair DXw[3] = {}, DYw[3] = {};
 
-    uint32_t L[3][3] = {};                         // source rows of a group: consumed by the gray conversion at the
+    uint32_t L[3][NL] = {};                        // source rows of a group: consumed by the gray conversion at the
                                                    // top of the group, then reloaded with the next group's rows
     uint32_t pend[3] = {};                         // plane bytes of the group just finished (strong | weak << 8)
     // A row is one 12-byte buffer load per lane: the frame as the buffer, the lane's column offset in a vector
     // register that never changes, the row's offset in a scalar register -- no vector arithmetic per load.
-    const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fsrc), 0, 3 * W * H, 0x00020000);
-    auto load_row = [&](int v, uint32_t (&r)[3]) {
+    const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fsrc), 0, (int)frame_bytes, 0x00020000);
+    auto load_row = [&](int v, uint32_t (&r)[NL]) {
         const int rs = !FE ? v : BLUR ? reflect101s(v, H) : (v < 0 ? 0 : (v >= H ? H - 1 : v));
-        const auto q = __builtin_amdgcn_raw_buffer_load_b96(frame, lane_off, (uint32_t)rs * (uint32_t)(3 * W), 0);
-        r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
+        if constexpr (DEC3) {
+            // pixel i of the lane is source bytes 9 i + 3 .. 9 i + 5 of the lane's 36: dwords 0-1, 3, 5 and 7-8 hold them
+            const uint32_t row = (uint32_t)(3 * rs + 1) * (uint32_t)(9 * W);
+            const auto q0 = __builtin_amdgcn_raw_buffer_load_b64(frame, lane_off, row, 0);
+            const uint32_t q1 = __builtin_amdgcn_raw_buffer_load_b32(frame, lane_off + 12u, row, 0);
+            const uint32_t q2 = __builtin_amdgcn_raw_buffer_load_b32(frame, lane_off + 20u, row, 0);
+            const auto q3 = __builtin_amdgcn_raw_buffer_load_b64(frame, lane_off + 28u, row, 0);
+            r[0] = q0[0]; r[1] = q0[1]; r[2] = q1; r[3] = q2; r[4] = q3[0]; r[5] = q3[1];
+        } else {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b96(frame, lane_off, (uint32_t)rs * (uint32_t)(3 * W), 0);
+            r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
+        }
     };
     // Dirty tracking of the plane rows (rowflags != null; the planes then start all zero and only this kernel and the
     // hysteresis kernel, which adds strong bits where weak ones are, write them): strip rows whose bytes were zero
@@ -259,17 +276,23 @@ __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, cons
     // ---- gray: 4 pixels (12 bytes) of source row v -> the gray bytes packed in one dword (BLUR, GATE, INTER) or
     // ---- directly as the pairs e = (px0, px2), o = (px1, px3) ------------------------------------------------
     constexpr bool PACKED_GRAY = BLUR || GATE != 0 || INTER;
-    auto gray_row = [&](const uint32_t (&r)[3], const int v) -> Pair {
-        const uint32_t w0 = r[0], w1 = r[1], w2 = r[2];
-        // pixel 3 sits in bytes 1..3 of w2: it takes the weights moved up a byte instead of a shifted copy
-        const uint32_t p0 = w0, p1 = alignbyte(w1, w0, 3), p2 = alignbyte(w2, w1, 2);
+    auto gray_row = [&](const uint32_t (&r)[NL], const int v) -> Pair {
+        // the four pixels as dwords whose low three bytes are the channels (pixel 2 and, without the reduction, pixel
+        // 3 sit a byte up in their dword: they take the weights moved up a byte instead of a shifted copy)
+        uint32_t p0, p1, p2, p3, k2lo = a.k_lo, k2hi = a.k_hi, k3lo = a.k_lo << 8, k3hi = a.k_hi << 8;
+        if constexpr (DEC3) {
+            p0 = alignbyte(r[1], r[0], 3); p1 = r[2]; p2 = r[3]; p3 = alignbyte(r[5], r[4], 2);
+            k2lo = a.k_lo << 8; k2hi = a.k_hi << 8; k3lo = a.k_lo; k3hi = a.k_hi;
+        } else {
+            p0 = r[0]; p1 = alignbyte(r[1], r[0], 3); p2 = alignbyte(r[2], r[1], 2); p3 = r[2];
+        }
         // the four low-byte sums first, then their shifts, then the four high-byte sums: a v_dot4 result is not
         // ready for a different kind of instruction at once
         const uint32_t l0 = dot4(p0, a.k_lo, 1u << 15), l1 = dot4(p1, a.k_lo, 1u << 15);
-        const uint32_t l2 = dot4(p2, a.k_lo, 1u << 15), l3 = dot4(w2, a.k_lo << 8, 1u << 15);
+        const uint32_t l2 = dot4(p2, k2lo, 1u << 15), l3 = dot4(p3, k3lo, 1u << 15);
         const uint32_t t0 = dot4(p0, a.k_hi, l0 >> 8), t1 = dot4(p1, a.k_hi, l1 >> 8);
-        const uint32_t t2 = dot4(p2, a.k_hi, l2 >> 8), t3 = dot4(w2, a.k_hi << 8, l3 >> 8);
-        const uint32_t p3 = GATE != 0 ? w2 >> 8 : 0u;
+        const uint32_t t2 = dot4(p2, k2hi, l2 >> 8), t3 = dot4(p3, k3hi, l3 >> 8);
+        if constexpr (GATE != 0) p3 >>= 8;
         Pair g;
         if constexpr (PACKED_GRAY) {
             uint32_t G = __builtin_amdgcn_perm(t1, t0, 0x0c0c0501u) | __builtin_amdgcn_perm(t3, t2, 0x05010c0cu);
@@ -437,7 +460,7 @@ __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, cons
     store_group(v - 3 - DB - 2, pend, pf);
 }
 
-template <bool BLUR, int GATE, bool INTER>
+template <bool BLUR, int GATE, bool INTER, bool DEC3 = false>
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     // Workgroups go round-robin over the 8 XCDs, each with its own L2.  Neighbouring strips share the cache lines
     // their rows meet in (a strip row is 744 bytes, not a multiple of 128) and the plane bytes they write, so
@@ -454,11 +477,11 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const bool hb = STRIP * s - 4 < 0 || ((a.g.W - (STRIP * s - 4)) >> 2) <= 63;
     const bool fe = y0 == 0 || y1 + DB + 1 >= H;        // rows y0 - DB - 2 .. y1 + DB + 1 are loaded
     if (hb) {
-        if (fe) front_unit<BLUR, GATE, INTER, true, true>(a, f, s, y0, y1);
-        else front_unit<BLUR, GATE, INTER, true, false>(a, f, s, y0, y1);
+        if (fe) front_unit<BLUR, GATE, INTER, true, true, DEC3>(a, f, s, y0, y1);
+        else front_unit<BLUR, GATE, INTER, true, false, DEC3>(a, f, s, y0, y1);
     } else {
-        if (fe) front_unit<BLUR, GATE, INTER, false, true>(a, f, s, y0, y1);
-        else front_unit<BLUR, GATE, INTER, false, false>(a, f, s, y0, y1);
+        if (fe) front_unit<BLUR, GATE, INTER, false, true, DEC3>(a, f, s, y0, y1);
+        else front_unit<BLUR, GATE, INTER, false, false, DEC3>(a, f, s, y0, y1);
     }
 }
 
@@ -469,7 +492,7 @@ int front_stream_strips(Geo g) { return (TILE * g.TX + STRIP - 1) / STRIP; }
 
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
-                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags) {
+                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags, bool dec3) {
     FrontArgs a;
     a.wake = wake;
     a.rowflags = rowflags;
@@ -505,7 +528,10 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     const bool inter = gray_out || blur_out;
 #define LC_FS(B, G, I) hipLaunchKernelGGL((k_front_stream<B, G, I>), grid, block, 0, st, a)
 #define LC_FS2(B, G) do { if (inter) LC_FS(B, G, true); else LC_FS(B, G, false); } while (0)
-    if (gate) { if (blur) LC_FS2(true, 1); else LC_FS2(false, 1); }
+    if (dec3) {   // src holds frames of 3 W x 3 H (the caller checked: no gate, no intermediates)
+        if (blur) hipLaunchKernelGGL((k_front_stream<true, 0, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_front_stream<false, 0, false, true>), grid, block, 0, st, a);
+    } else if (gate) { if (blur) LC_FS2(true, 1); else LC_FS2(false, 1); }
     else { if (blur) LC_FS2(true, 0); else LC_FS2(false, 0); }
 #undef LC_FS2
 #undef LC_FS

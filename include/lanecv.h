@@ -215,7 +215,9 @@ typedef struct lc_pipe_params {
 #define LC_BUF_MASKED   4     /* uint8  [n][h][w]   edge map after car mask and ROI */
 #define LC_BUF_ACC      5     /* int32  [n][numangle][numrho] (want_accumulator) */
 #define LC_BUF_NPOINTS  6     /* int32  [n]         non-zero pixels of the masked edge map */
-#define LC_BUF_RESIZED  7     /* uint8  [n][h][w][3] the frames after the leading resize (src_width / src_height set) */
+#define LC_BUF_RESIZED  7     /* uint8  [n][h][w][3] the frames after the leading resize (src_width / src_height set;
+                                 an exact reduction by three is read by the edge kernel directly and only
+                                 materialised with keep_intermediates) */
 
 /* Stages timed with HIP events on the slot's stream (lc_pipe_stage_ms). */
 #define LC_STAGE_UPLOAD 0

@@ -39,15 +39,18 @@ def test_resize_errors(cv2):
         cv2.resize(img.astype(np.float32), (4, 4))
 
 
-@pytest.mark.parametrize("src", [(1920, 1080), (1280, 720), (640, 360), (700, 500)])
-def test_f1_frame_to_curves(cv2, oracle, src):
+@pytest.mark.parametrize("src,keep", [((1920, 1080), False), ((1920, 1080), True), ((1280, 720), True), ((1280, 720), False),
+                                      ((640, 360), False), ((700, 500), False)])
+def test_f1_frame_to_curves(cv2, oracle, src, keep):
     """`process_frame` + `detect_and_draw` up to the fitted curves: resize -> BGR2GRAY -> blur -> Canny(50,150)
     -> car mask -> trapezoid -> nonzero -> mid-x split -> memory fit, pipeline against oracle + NumPy."""
     from lanecv import synth, _abi, glue
     from lanecv.pipeline import LanePipeline, Recipe
     w, h = 640, 360
     rec = Recipe.f1(w, h)
-    pipe = LanePipeline(w, h, rec, max_batch=4, nslots=2, src_size=src, keep_intermediates=(src[0] == 1280))
+    # (1920 x 1080 without intermediates: the reduction by three is fused into the edge kernel, no resized frame exists)
+    pipe = LanePipeline(w, h, rec, max_batch=4, nslots=2, src_size=src, keep_intermediates=keep)
+    fused = src == (1920, 1080) and not keep
     frames = np.stack([synth.synth_road(src[0], src[1], seed=6, t=t) for t in range(3)] +
                       [synth.adversarial_frames(src[0], src[1])["noise"]])
     got_trk, want_trk = glue.PixelCurveTracker(), glue.PixelCurveTracker()
@@ -56,11 +59,14 @@ def test_f1_frame_to_curves(cv2, oracle, src):
         pipe.submit(rep, batch)
         pipe.wait(rep)
         masked = pipe.read(rep, _abi.BUF_MASKED)
-        small = pipe.read(rep, _abi.BUF_RESIZED) if src != (w, h) else batch
+        if fused:
+            with pytest.raises(cv2.error):
+                pipe.read(rep, _abi.BUF_RESIZED)
+        small = pipe.read(rep, _abi.BUF_RESIZED) if src != (w, h) and not fused else None
         nz = pipe.nonzero(rep)
         for i, f in enumerate(batch):
             fr = oracle.resize_linear(f, (w, h))
-            assert (small[i] == fr).all(), i
+            assert small is None or (small[i] == fr).all(), i
             r = oracle.lane_frame(fr, rec.color_code, rec.blur, rec.canny[0], rec.canny[1], pipe.roi, rec.rho, rec.theta,
                                   rec.threshold, rec.min_line_length, rec.max_line_gap, car_mask=rec.car_mask,
                                   want_acc=False, want_segments=False)
