@@ -119,6 +119,7 @@ struct Work {
     DevBuf<uint8_t> rowflags;     // streaming front kernel's dirty flags of the plane rows (pipeline slots)
     DevBuf<uint32_t> wake;        // two wake-flag arrays of B * tiles words (hysteresis closure)
     DevBuf<int> rounds, rowcount, npoints, segcount, status, fallback;
+    DevBuf<int> redo;             // per frame: the pass over the lower rows only was not enough (pipelines that skip rows)
     DevBuf<uint32_t> nz;
     int nz_cap = 0;
     DevBuf<int32_t> acc_full, acc_ppht, seg;
@@ -180,7 +181,9 @@ struct Work {
         HIP_TRY(hipMemset(rowcount.p, 0, sizeof(int) * (size_t)B * H));
         if ((rc = npoints.alloc(B))) return rc;
         if ((rc = segcount.alloc(B))) return rc;
-        if ((rc = status.alloc(3))) return rc;
+        if ((rc = status.alloc(4))) return rc;
+        if ((rc = redo.alloc(B))) return rc;
+        HIP_TRY(hipMemset(redo.p, 0, sizeof(int) * (size_t)B));
         if ((rc = fallback.alloc(B))) return rc;
         return LC_OK;
     }
@@ -1041,7 +1044,7 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
     const int na = wk.hg.numangle, nr = wk.hg.numrho;
     if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
     if ((rc = points_from_bytes(ctx, nullptr))) return rc;
-    HIP_TRY(hipMemsetAsync(wk.status.p, 0, 3 * sizeof(int), ctx->stream));
+    HIP_TRY(hipMemsetAsync(wk.status.p, 0, 4 * sizeof(int), ctx->stream));
     const int line_length = (int)lrint(min_line_length), line_gap = (int)lrint(max_line_gap);
     const bool fast = launch_ppht_fast(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, threshold, line_length,
                                        line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, RNG_TABLE,
@@ -1124,6 +1127,14 @@ struct lc_pipe {
     // second one gained nothing there); LANECV_LINES_STREAMS overrides the count.
     std::vector<hipStream_t> st_lines_more;
     unsigned lines_turn = 0;
+    // The streaming front kernel's unit height (fixed for the pipeline's largest batch: its change tracking is per unit)
+    // and, for pipelines whose ROI begins far down the frame, the row above which pixels are not classified at all:
+    // the final edge map is the hysteresis result INSIDE the ROI, and that depends on rows above the ROI only through
+    // weak pixels that connect the two.  The front kernel starts at row_split, BAND rows above the ROI's first row;
+    // launch_band_check proves per frame that no such connection can exist (a row of the band without leftover weak
+    // pixels), and the rare frame it cannot prove it for is classified again from row 0.  Not with intermediates
+    // (the pre-ROI edge map must then be complete).
+    int front_rows = 0, row_split = 0, roi_first_row = 0;
     bool fuse_vote = true;        // HoughLinesP's kernel also produces the full-vote accumulator (in LDS, before its own)
     // HoughLinesP with half a CU's LDS per frame, so that two frames -- of two batches, on two streams -- share a CU:
     // the kernel is one sequential wavefront per frame and leaves most of a CU idle.  For frame sizes whose working
@@ -1235,14 +1246,25 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
         s.input = w.bgr.p;
         s.input_bytes = (size_t)n * 3 * w.npix;
     }
+    const FrontSplit skip{pp->row_split, 1, nullptr}, again{pp->row_split, 0, w.redo.p};
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
-                 pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize);
+                 pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize, pp->front_rows,
+                 pp->row_split > 0 ? &skip : nullptr);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
     hipStream_t ps = pp->st_post;
     if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, s.ev[EV_FRONT], 0));
     launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status);
+    if (pp->row_split > 0) {
+        // frames for which the lower rows alone do not settle the ROI's edges: all rows again, and their hysteresis
+        // (both launches leave at once for the other frames, which is nearly always all of them)
+        launch_band_check(w.g, n, w.planeS.p, w.planeW.p, pp->row_split, pp->roi_first_row, w.redo.p, w.r_status, ps);
+        launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
+                     w.wake.p, nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p,
+                     fused_resize, pp->front_rows, &again);
+        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p);
+    }
     HIP_TRY(hipEventRecord(s.ev[EV_HYST], ps));
     if (pp->deferred >= 0) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_HYST]); pp->deferred = -1; }
     enqueue_back(pp, s);
@@ -1309,6 +1331,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     pp->line_length = (int)lrint(p.min_line_length);
     pp->line_gap = (int)lrint(p.max_line_gap);
     if (const char *fv = getenv("LANECV_VOTE_FUSED")) pp->fuse_vote = fv[0] != '0';
+    pp->front_rows = front_stream_rows_per_unit(pp->g, p.max_batch);
     pp->ppht_two_per_cu = p.want_segments && (size_t)p.width * p.height <= 2600000 && p.nslots >= 3;
     if (const char *tp = getenv("LANECV_PPHT_TWO_PER_CU")) pp->ppht_two_per_cu = tp[0] != '0';   // diagnostics
 
@@ -1342,6 +1365,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     if (p.roi_mask || p.car_mask) {
         const Geo g = pp->g;
         std::vector<uint64_t> bits(g.plane_words(), 0);
+        int roi_first = -1;
         for (int y = 0; y < g.H; y++)
             for (int x = 0; x < g.W; x++) {
                 size_t i = (size_t)y * g.W + x;
@@ -1355,14 +1379,25 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
                     keep = v != 0;
                 }
                 if (keep && p.car_mask) keep = p.car_mask[i] != 0;
-                if (keep) bits[(size_t)y * g.TX + (x >> 6)] |= 1ull << (x & 63);
+                if (keep) {
+                    bits[(size_t)y * g.TX + (x >> 6)] |= 1ull << (x & 63);
+                    if (roi_first < 0) roi_first = y;
+                }
             }
+        pp->roi_first_row = roi_first < 0 ? g.H : roi_first;
         if ((rc = pp->roi_bits.alloc(bits.size()))) { delete pp; return rc; }
         hipError_t e = hipMemcpy(pp->roi_bits.p, bits.data(), bits.size() * 8, hipMemcpyHostToDevice);
         if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "roi upload failed: %s", hipGetErrorString(e)); }
         pp->has_roi = true;
     }
 
+    {
+        constexpr int BAND = 16;            // rows between row_split and the ROI in which a clean row is looked for
+        static const char *ns = getenv("LANECV_NO_ROW_SKIP");
+        if (pp->has_roi && !p.keep_intermediates && front_stream_supported(pp->g) && !getenv("LANECV_FRONT_TILED") && !ns &&
+            pp->roi_first_row - BAND >= 64)
+            pp->row_split = pp->roi_first_row - BAND;
+    }
     {
         // All streams have the same priority.  With the post and HoughLinesP streams at high priority their few
         // workgroups were placed ahead of a front kernel's thousands a little sooner (327 k against 320 k frames/s at
@@ -1676,6 +1711,23 @@ int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_to
     for (int i = 0; i < s->nframes; i++) { mx = std::max(mx, s->h_rounds[i]); tot += s->h_rounds[i]; }
     if (rounds_max) *rounds_max = mx;
     if (rounds_total) *rounds_total = tot;
+    return LC_OK;
+}
+
+int lc_pipe_row_skip(lc_pipe *pipe, int slot, int *first_row, int *frames_redone) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
+    if (first_row) *first_row = pipe->row_split;
+    if (frames_redone) {
+        *frames_redone = 0;
+        if (pipe->row_split > 0 && s->nframes > 0) {
+            std::vector<int> redo(s->nframes);
+            HIP_TRY(hipMemcpy(redo.data(), s->w.redo.p, sizeof(int) * s->nframes, hipMemcpyDeviceToHost));
+            for (int v : redo) *frames_redone += v != 0;
+        }
+    }
     return LC_OK;
 }
 

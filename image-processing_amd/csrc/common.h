@@ -77,11 +77,21 @@ void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_
 // streaming front kernel (kernels_front_stream.hip): interleaved 3-channel input, W % 4 == 0
 bool front_stream_supported(Geo g);
 int front_stream_strips(Geo g);     // 248-column strips per frame row
+int front_stream_rows_per_unit(Geo g, int max_batch);
+// Rows the final edge map cannot depend on need not be classified.  With an ROI whose first row is far down the frame, a
+// pipeline splits the frame at row_split: a launch with skip_top classifies rows >= row_split only (the units above
+// only clear what a full pass left behind); launch_band_check then decides per frame whether that was enough, and a
+// second launch without skip_top and with only_frames redoes the frames for which it was not.
+struct FrontSplit {
+    int row_split;              // > 0: first row of the lower region
+    int skip_top;               // 1: do not classify rows above row_split
+    const int *only_frames;     // device flags, one per frame, or null: frames whose flag is 0 are left alone
+};
 // gate (may be null): the colour gate applied to the frame before the gray conversion; tab as above
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                          int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags = nullptr,
-                         bool dec3 = false);
+                         bool dec3 = false, const FrontSplit *split = nullptr);
 // dec3: src holds frames of 3 W x 3 H pixels; the kernel takes source pixel (3x + 1, 3y + 1) for pixel (x, y), which is
 // what cv2.resize's bilinear reduction by exactly three yields (no gate, no intermediate images in this form)
 void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st);
@@ -97,7 +107,9 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
                   int low, int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake,
                   uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
                   const GateDev *gate = nullptr, const int *tab = nullptr, uint8_t *gate_gray = nullptr,
-                  uint8_t *rowflags = nullptr, bool dec3 = false);
+                  uint8_t *rowflags = nullptr, bool dec3 = false, int rows_per_unit = 0, const FrontSplit *split = nullptr);
+// rows_per_unit (streaming kernel; 0 = derived from nframes): pipelines pass the value of their largest batch, so that
+// the unit grid -- and with it the per-unit change tracking behind rowflags -- does not move with the batch size
 // hysteresis to the fixed point: one workgroup per frame floods the tiles flagged in wake (by the front
 // kernel: those with weak pixels), then repeats over the tiles whose neighbours gained a strong border pixel
 // until a round flags none; rounds[f] receives the rounds frame f needed.  wake holds two arrays of
@@ -105,7 +117,14 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 // status (may be null): three words this kernel zeroes; the kernels behind it on the stream raise them with plain stores
 // ([0], [1]: launch_points; [2]: a frame did not fit the LDS the fast HoughLinesP kernel was launched with)
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
-                       hipStream_t st, int *status = nullptr);
+                       hipStream_t st, int *status = nullptr, const int *only_frames = nullptr);
+// only_frames (may be null): device flags, one per frame; frames whose flag is 0 are left alone
+// After hysteresis over the rows >= row_split only: redo[f] = 1 if none of the rows [row_split, roi_first_row) of frame f
+// is free of weak pixels that stayed weak.  (A connection from an ROI pixel to a strong pixel above row_split would have
+// to pass through such a pixel in every one of those rows; one clean row proves there is none.)  status (may be null):
+// word 3 is set if any frame was flagged.
+void launch_band_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, int row_split, int roi_first_row,
+                       int *redo, int *status, hipStream_t st);
 // roi_bits: one plane shared by all frames, or nullptr
 // prevbits (may be null): the masked bits of the previous call on the same masked_out / rowplane buffers, all
 // zero before the first (like those buffers); with it, and without edges_out, only what changed is written

@@ -419,10 +419,37 @@ __device__ __forceinline__ void hysteresis_frame(const Geo &g, int f, uint64_t *
 __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__restrict__ planeS,
                                                            const uint64_t *__restrict__ planeW,
                                                            uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
-                                                           int *__restrict__ rounds_out, int *__restrict__ status) {
+                                                           int *__restrict__ rounds_out, int *__restrict__ status,
+                                                           const int *__restrict__ only_frames) {
     __shared__ int any;
-    if (status && blockIdx.x == 0 && threadIdx.x == 0) status[0] = status[1] = status[2] = 0;   // raised by the kernels behind this one
+    // (the status words are raised by the kernels behind this one; a launch for a few frames only is such a kernel)
+    if (status && !only_frames && blockIdx.x == 0 && threadIdx.x == 0) status[0] = status[1] = status[2] = status[3] = 0;
+    if (only_frames && only_frames[blockIdx.x] == 0) return;
     hysteresis_frame(g, blockIdx.x, planeS, planeW, wakeA, wakeB, rounds_out, any);
+}
+
+// ---------------------------------------------------------------------------
+// Was it enough to classify the rows from row_split down?  One wavefront per frame looks at the rows between
+// row_split and the first row of the ROI: a row without a weak pixel that stayed weak separates everything below it
+// from whatever lies above row_split (see launch_band_check in common.h).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_band_check(Geo g, const uint64_t *__restrict__ planeS, const uint64_t *__restrict__ planeW,
+                                                   int row_split, int roi_first_row, int *__restrict__ redo,
+                                                   int *__restrict__ status) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    bool clean_row = false;
+    for (int y = row_split; y < roi_first_row && !clean_row; y++) {
+        uint64_t left = 0;
+        for (int tx = lane; tx < g.TX; tx += 64) {
+            const size_t i = ((size_t)f * g.H + y) * g.TX + tx;
+            left |= planeW[i] & ~planeS[i];
+        }
+        clean_row = __ballot(left != 0) == 0;
+    }
+    if (lane == 0) {
+        redo[f] = clean_row ? 0 : 1;
+        if (!clean_row && status) status[3] = 1;        // (a plain store: the words may live in host memory)
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -587,12 +614,13 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes, int low,
                   int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
-                  hipStream_t st, const GateDev *gate, const int *tab, uint8_t *gate_gray, uint8_t *rowflags, bool dec3) {
+                  hipStream_t st, const GateDev *gate, const int *tab, uint8_t *gate_gray, uint8_t *rowflags, bool dec3,
+                  int rows_per_unit, const FrontSplit *split) {
     static const char *force_tiled = getenv("LANECV_FRONT_TILED");       // diagnostics: use the tiled kernel everywhere
     static const char *rows_env = getenv("LANECV_FRONT_ROWS");           // tuning: rows per streaming unit
     if (in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1')) {
         launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, wake, gray_out, blur_out,
-                            rows_env ? atoi(rows_env) : 0, gate, tab, st, rowflags, dec3);
+                            rows_env ? atoi(rows_env) : rows_per_unit, gate, tab, st, rowflags, dec3, split);
         return;
     }
     if (gate && in_kind == 1) {   // gated gray first, then the tiled kernel on that gray image
@@ -610,11 +638,16 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 }
 
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
-                       hipStream_t st, int *status) {
+                       hipStream_t st, int *status, const int *only_frames) {
     // wake holds two flag arrays of nframes * tiles words each.  The second is all zero on entry and both are on
     // exit (zeroed when allocated): the kernel clears every flag it consumes and stops when a round sets none.
     const int nt = g.TX * g.TY * nframes;
-    hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds, status);
+    hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds, status, only_frames);
+}
+
+void launch_band_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, int row_split, int roi_first_row,
+                       int *redo, int *status, hipStream_t st) {
+    hipLaunchKernelGGL(k_band_check, dim3(nframes), dim3(64), 0, st, g, planeS, planeW, row_split, roi_first_row, redo, status);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,

@@ -13,28 +13,27 @@
 // three-row windows indexed by the phase, so no register is ever copied to age a window.  Sixteen-bit
 // values live as pairs: `e` = (pixel 0, pixel 2), `o` = (pixel 1, pixel 3) of the lane.
 //
-// Instruction choice.  On gfx950 a SIMD issues the plain 32-bit v_add / v_sub / v_and / v_or / v_xor /
-// v_lshrrev / v_bitop3 at twice the rate of everything else this kernel could use (packed 16-bit math, v_dot4,
-// v_perm, v_alignbyte, DPP moves, three-operand integer forms: 4 cycles per wavefront instruction against 2,
-// measured by tools/valu_rate.hip), and the kernel is bound by vector issue.  So wherever the two halves of a
-// pair cannot disturb each other, a pair is handled by ONE 32-bit instruction: sums of non-negative halves that
-// stay below 2^16, and differences that are kept non-negative by a bias in each half.  Signed quantities
-// therefore travel with a bias (dx + 0x1000, dy + 0x0800, magnitude + 0x1800) that is taken off, or
-// compared against equally biased thresholds, where it matters.
+// Instruction choice.  The kernel is bound by vector instruction issue, not by memory: what counts is the number of
+// vector instructions per row, then the number of scalar ones (the four SIMDs of a CU share one scalar unit).  On
+// gfx950 a SIMD takes the plain 32-bit v_add / v_sub / v_and / v_or / v_xor / v_lshrrev / v_bitop3 at twice the rate
+// of everything else used here (packed 16-bit math, v_dot4, v_perm, v_alignbyte, DPP moves, three-operand integer
+// forms: 4 cycles per wavefront instruction against 2 -- tools/valu_rate.hip), but only among their like: mixed
+// with the others, as here, they come out about a tenth cheaper.  So a pair of 16-bit halves is handled by ONE
+// 32-bit instruction wherever the halves cannot disturb each other (sums of non-negative halves that stay below
+// 2^16) and the count is the same as for the packed form; signed quantities stay packed.
 //
 // Arithmetic (bit-exact with OpenCV's 8U paths):
 //   gray   with doubled weights 2k = 256 k_hi + k_lo:  S = sum c_i k_hi_i + ((sum c_i k_lo_i + 2^15) >> 8) by two
 //          chained v_dot4_u32_u8; gray = byte 1 of S  (= (sum c_i k_i + 2^14) >> 15)
 //   blur   [1 4 6 4 1] horizontally by v_dot4 (+8); vertically as four running pair sums
 //          A(v) = H(v-1) + H(v), T(v) = A(v-1) + A(v), C(v) = T(v-1) + T(v), B(v) = C(v-1) + C(v) = 16 * ([1 4 6 4 1]
-//          over rows v-4 .. v) + 128, all below 2^16; blurred value = B >> 8
-//   Sobel  separable: d = b(x+1) - b(x-1) + 0x400, s = b(x-1) + 2 b(x) + b(x+1) per row;
-//          P(b) = d(b-1) + d(b), dx + 0x1000 = P(m) + P(m+1); dy + 0x800 = (s(m+1) | 0x800) - s(m-1);
-//          |dx| + 0x1000 = max(dx', 0x2000 - dx'), |dy| + 0x800 likewise, magnitude' = their sum (+ 0x1800)
+//          over rows v-4 .. v) + 128, all below 2^16; blurred value = B >> 8 (one v_perm takes both halves' high bytes)
+//   Sobel  separable, packed i16: d = b(x+1) - b(x-1), s = b(x-1) + 2 b(x) + b(x+1) per row;
+//          P(b) = d(b-1) + d(b), dx = P(m) + P(m+1); dy = s(m+1) - s(m-1); magnitude |dx| + |dy|
 //   NMS    direction by the exact 16-bit form of OpenCV's 15-bit tan(22.5) test:
 //          q = floor(|dx| * 13573 / 2^15) = (|dx| * 53 + (|dx| * 5 >> 8)) >> 7   (13573 = 53 * 256 + 5)
 //          horizontal  <=>  |dy| < q + min(|dx|, 1);   vertical  <=>  |dy| > 2 |dx| + q
-//          "m > x" is bit 15 of (m | 0x8000) - 1 - x (one 32-bit subtraction per pair); selections are v_bitop3
+//          "m > x" is bit 15 of m + 0x7FFF - x (one 32-bit subtraction per pair); selections are v_bitop3
 //   borders: gray reflects (101) for the blur, the Sobel input replicates, magnitudes outside the image are 0
 // Requires W % 4 == 0 (lanes are then wholly inside or wholly outside the image); other widths and
 // gray input take the tiled kernel in kernels_edge.hip.
@@ -65,7 +64,7 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot4(a, b, c, false);
 }
-// three-input bit operations (v_bitop3_b32, a double-rate instruction): T = truth table with a = 0xF0, b = 0xCC, c = 0xAA
+// three-input bit operations (v_bitop3_b32): T = truth table with a = 0xF0, b = 0xCC, c = 0xAA
 template <int T> __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_bitop3_b32(a, b, c, T);
 }
@@ -75,8 +74,8 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return bitop3<0xEA>(a, b, c); }   // (a & b) | c
 __device__ __forceinline__ uint32_t or_and(uint32_t a, uint32_t b, uint32_t c) { return bitop3<0xA8>(a, b, c); }   // (a | b) & c
 // 32-bit add / subtract on a pair of 16-bit halves that cannot carry or borrow into each other.  Inline assembly
-// so that the optimiser does not merge them back into three-operand or shifting forms, which issue at half the
-// rate.  (Their results never feed a DPP move or a lane read directly, and they never consume a v_dot4 result
+// so that the optimiser does not merge them into three-operand or shifting forms (no fewer instructions, and the
+// slower kind).  (Their results never feed a DPP move or a lane read directly, and they never consume a v_dot4 result
 // directly: the compiler's hazard bookkeeping does not look inside assembly statements.)
 __device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) {
     uint32_t r;
@@ -144,6 +143,10 @@ struct FrontArgs {
     uint32_t *wake;          // per 64x64 tile: set where a weak pixel is stored (the hysteresis kernel's work list)
     uint8_t *rowflags;       // [frame][strip][row]: the plane bytes last stored for that strip row were not all zero; or null
     int rows_per_unit, nseg, nstrips, nunits;
+    // rows [0, row_split) form a region of their own with nseg_top units of rows_top rows (0: no such region).
+    // skip_top: those units only clear what an earlier full pass left in their plane rows (see FrontSplit).
+    int row_split, nseg_top, rows_top, skip_top;
+    const int *only_frames;  // if set: frames whose word is zero are left alone
     int wg_chunk;            // logical workgroups per XCD (see the kernel)
     const int *gate_tab;     // GATE only: the gate's tables in device memory (gate_tables_host)
     GateDev gate;
@@ -460,6 +463,33 @@ __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, cons
     store_group(v - 3 - DB - 2, pend, pf);
 }
 
+// A unit of the skipped top region: nothing is computed, but plane rows an earlier full pass over this frame slot
+// stored there (flagged in rowflags, group by group as front_unit does it) are zeroed again, so that the planes
+// above row_split read as empty.
+template <bool BLUR>
+__device__ __forceinline__ void clear_unit(const FrontArgs &a, const int f, const int s, const int y0, const int y1) {
+    if (!a.rowflags) return;
+    constexpr int DB = BLUR ? 2 : 0;
+    const int lane = threadIdx.x & 63, H = a.g.H, TX = a.g.TX;
+    const int bi = STRIP / 8 * s + ((lane - 1) >> 1);
+    const bool stores = (lane & 1) && lane <= 61 && bi < 8 * TX;
+    const size_t flag_base = ((size_t)f * a.nstrips + s) * H;
+    const int vend = y1 - 1 + DB + 2;
+    for (int v = y0 - (DB + 2); v <= vend + 3; v += 3) {
+        const int n0 = v - 3 - DB - 2;
+        if (n0 + 2 < y0 || n0 >= y1) continue;
+        const size_t fi = flag_base + (size_t)min(max(n0 + 1, y0), y1 - 1);
+        if (a.rowflags[fi] == 0) continue;
+        for (int k = 0; k < 3; k++) {
+            const int n_row = n0 + k;
+            if (n_row < y0 || n_row >= y1 || !stores) continue;
+            reinterpret_cast<uint8_t *>(a.planeS)[((size_t)f * H + n_row) * TX * 8 + bi] = 0;
+            reinterpret_cast<uint8_t *>(a.planeW)[((size_t)f * H + n_row) * TX * 8 + bi] = 0;
+        }
+        if (lane == 0) a.rowflags[fi] = 0;
+    }
+}
+
 template <bool BLUR, int GATE, bool INTER, bool DEC3 = false>
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     // Workgroups go round-robin over the 8 XCDs, each with its own L2.  Neighbouring strips share the cache lines
@@ -471,8 +501,15 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const int s = u % a.nstrips;
     const int sg = (u / a.nstrips) % a.nseg;
     const int f = u / (a.nstrips * a.nseg);
+    if (a.only_frames && a.only_frames[f] == 0) return;
     const int H = a.g.H;
-    const int y0 = sg * a.rows_per_unit, y1 = min(y0 + a.rows_per_unit, H);
+    int y0, y1;
+    if (sg < a.nseg_top) {
+        y0 = sg * a.rows_top; y1 = min(y0 + a.rows_top, a.row_split);
+        if (a.skip_top) { clear_unit<BLUR>(a, f, s, y0, y1); return; }
+    } else {
+        y0 = a.row_split + (sg - a.nseg_top) * a.rows_per_unit; y1 = min(y0 + a.rows_per_unit, H);
+    }
     constexpr int DB = BLUR ? 2 : 0;
     const bool hb = STRIP * s - 4 < 0 || ((a.g.W - (STRIP * s - 4)) >> 2) <= 63;
     const bool fe = y0 == 0 || y1 + DB + 1 >= H;        // rows y0 - DB - 2 .. y1 + DB + 1 are loaded
@@ -490,9 +527,22 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
 bool front_stream_supported(Geo g) { return g.W % 4 == 0 && g.W >= 8; }
 int front_stream_strips(Geo g) { return (TILE * g.TX + STRIP - 1) / STRIP; }
 
+// rows per unit of the streaming kernel for batches of up to `max_batch` frames: enough units to load every CU many
+// times over (80 per CU measured best beside HoughLinesP: finer units balance better around its resident workgroups),
+// few enough to keep the 8 halo rows cheap.  A pipeline fixes it once: the kernel's change tracking is kept per unit.
+int front_stream_rows_per_unit(Geo g, int max_batch) {
+    const int nstrips = front_stream_strips(g);
+    int want = 20480 / (max_batch * nstrips > 0 ? max_batch * nstrips : 1);
+    if (want < 1) want = 1;
+    int rows = (g.H + want - 1) / want;
+    if (rows < 64) rows = 64;
+    return rows > g.H ? g.H : rows;
+}
+
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
-                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags, bool dec3) {
+                         int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags, bool dec3,
+                         const FrontSplit *split) {
     FrontArgs a;
     a.wake = wake;
     a.rowflags = rowflags;
@@ -505,17 +555,18 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.k_lo = (k0 & 255) | ((k1 & 255) << 8) | ((k2 & 255) << 16);
     a.k_hi = (k0 >> 8) | ((k1 >> 8) << 8) | ((k2 >> 8) << 16);
     a.nstrips = front_stream_strips(g);              // every byte of every plane row is covered
-    if (rows_per_unit <= 0) {
-        // enough units to load every CU many times over (80 per CU measured best beside HoughLinesP: finer units
-        // balance better around its resident workgroups), few enough to keep the 8 halo rows cheap
-        int want = 20480 / (nframes * a.nstrips > 0 ? nframes * a.nstrips : 1);
-        if (want < 1) want = 1;
-        rows_per_unit = (g.H + want - 1) / want;
-        if (rows_per_unit < 64) rows_per_unit = 64;
-    }
+    if (rows_per_unit <= 0) rows_per_unit = front_stream_rows_per_unit(g, nframes);
     if (rows_per_unit > g.H) rows_per_unit = g.H;
     a.rows_per_unit = rows_per_unit;
-    a.nseg = (g.H + rows_per_unit - 1) / rows_per_unit;
+    a.row_split = split ? split->row_split : 0;
+    a.skip_top = split ? split->skip_top : 0;
+    a.only_frames = split ? split->only_frames : nullptr;
+    a.nseg_top = a.rows_top = 0;
+    if (a.row_split > 0) {                           // the top region in units of about the same height
+        a.nseg_top = (a.row_split + rows_per_unit - 1) / rows_per_unit;
+        a.rows_top = (a.row_split + a.nseg_top - 1) / a.nseg_top;
+    }
+    a.nseg = a.nseg_top + (g.H - a.row_split + rows_per_unit - 1) / rows_per_unit;
     a.nunits = nframes * a.nseg * a.nstrips;
     // no LDS and no barrier: one wavefront per workgroup, so that a unit can start wherever a single wave slot
     // is free (LANECV_FRONT_WAVES overrides: waves per workgroup, 1..4)

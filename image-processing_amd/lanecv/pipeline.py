@@ -262,6 +262,12 @@ class LanePipeline:
         _abi.check(_abi.lib().lc_pipe_hyst_rounds(self._h, slot, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def row_skip(self, slot=0):
+        """(first row the edge kernel classifies, frames of the slot's last batch that needed all rows after all)."""
+        a, b = C.c_int(), C.c_int()
+        _abi.check(_abi.lib().lc_pipe_row_skip(self._h, slot, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def shared_queues(self):
         """Streams of the pipeline that found no hardware queue of their own (0 = full overlap)."""
         n = C.c_int()

@@ -294,6 +294,14 @@ def test_bench_launch_shape_parity(oracle):
             inflight.append((k, slot))
         for it in inflight:
             check(*it)
+        # a smaller batch into a used slot: the kernel's per-unit change tracking must not depend on the batch size
+        pipe.submit_device(0, dev[1].ptr.value, 100)
+        seg, cnt = pipe.wait(0)
+        masked = pipe.read(0, _abi.BUF_MASKED)
+        for i in range(100):
+            r = want[(i + rotations[1]) % ndistinct]
+            assert cnt[i] == len(r["segments"]) and np.array_equal(seg[i, :cnt[i]], r["segments"]), i
+            assert np.array_equal(masked[i], r["masked"]), i
     finally:
         pipe.close()
         for d in dev:
@@ -318,4 +326,49 @@ def test_temporaries_stay_alive_per_slot(oracle):
             r = _oracle_frame(oracle, np.ascontiguousarray(wide[s][i, :, ::2]), rec, pipe.roi)["segments"]
             got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
             assert got.shape == r.shape and (got == r).all(), (s, i)
+    pipe.close()
+
+
+def test_rows_above_the_roi_are_skipped_exactly(oracle):
+    """A pipeline whose ROI begins far down the frame classifies only the rows from a little above the ROI: per frame
+    it proves that nothing above can reach the ROI through weak pixels, and classifies the frame again from row 0
+    where it cannot.  Road frames must take the short way, frames built to need the rows above must be caught
+    (a faint vertical edge that is only made an edge by its strong upper end, far above the ROI), and a slot that
+    saw such a frame must be clean again for the next batch."""
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h = 960, 540
+    rec = Recipe.north_star(w, h)
+    pipe = LanePipeline(w, h, rec, max_batch=6, nslots=2, seg_capacity=512)
+
+    def faint_edge(x, ytop, flip=False):
+        g = np.full((h, w), 60, np.int32)
+        g[:ytop, x:] += 120                      # strong: 2.5 * 120 > 200
+        g[ytop:, x:] += 60                       # weak alone: 100 < 2.5 * 60 <= 200
+        f = np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+        return f[:, ::-1].copy() if flip else f
+
+    road = [synth.synth_road(w, h, seed=41, t=t) for t in range(4)]
+    first, redone = pipe.row_skip(0)
+    assert first == h // 2 - 16 and redone == 0
+    batches = [
+        np.stack(road),
+        np.stack([road[0], faint_edge(w // 2 + 40, 100), road[1], faint_edge(w // 2 + 90, 30, flip=True), road[2]]),
+        np.stack(road[::-1] + road[:2]),         # the same slot after frames that were redone: the rows above are clean again
+        np.stack([faint_edge(w // 2 + 40, 100)] * 3),
+        np.stack(road[:3]),
+    ]
+    want_redone = [0, 2, 0, 3, 0]
+    for b, frames in enumerate(batches):
+        assert np.count_nonzero(_oracle_frame(oracle, frames[1 if b in (1,) else 0], rec, pipe.roi)["masked"]) > 0
+        pipe.submit(0, frames)
+        segs = pipe.collect(0)
+        masked, acc = pipe.read(0, _abi.BUF_MASKED), pipe.read(0, _abi.BUF_ACC)
+        assert pipe.row_skip(0)[1] == want_redone[b], b
+        for i, f in enumerate(frames):
+            r = _oracle_frame(oracle, f, rec, pipe.roi)
+            assert (masked[i] == r["masked"]).all(), (b, i)
+            assert (acc[i] == r["acc"]).all(), (b, i)
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (b, i)
     pipe.close()
