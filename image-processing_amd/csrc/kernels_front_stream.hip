@@ -40,6 +40,7 @@
 #include "gate.h"
 #include <type_traits>
 #include <cstdlib>
+#include <algorithm>
 
 namespace lanecv {
 namespace {
@@ -146,7 +147,11 @@ struct FrontArgs {
     // rows [0, row_split) form a region of their own with nseg_top units of rows_top rows (0: no such region).
     // skip_top: those units only clear what an earlier full pass left in their plane rows (see FrontSplit).
     int row_split, nseg_top, rows_top, skip_top;
-    const int *only_frames;  // if set: frames whose word is zero are left alone
+    // if set: only the frames whose word is non-zero are done, and the grid is not one workgroup per unit of every
+    // frame but REDO_GROUPS per unit of ONE frame (nearly always no frame is flagged: 20 000 workgroups that only
+    // look at a flag would cost more than the check is worth); group j does the flagged frames j, j + GROUPS, ...
+    const int *only_frames;
+    int nframes;
     int wg_chunk;            // logical workgroups per XCD (see the kernel)
     const int *gate_tab;     // GATE only: the gate's tables in device memory (gate_tables_host)
     GateDev gate;
@@ -155,6 +160,7 @@ struct FrontArgs {
 struct Pair { uint32_t e, o; };   // 4 packed 16-bit values of a lane: e = (px0, px2), o = (px1, px3)
 
 constexpr int STRIP = 248;        // output columns of a wavefront
+constexpr int REDO_GROUPS = 8;    // workgroups per unit of a launch that does flagged frames only
 
 template <int P> using Phase = std::integral_constant<int, P>;
 
@@ -500,25 +506,41 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     if (u >= a.nunits) return;
     const int s = u % a.nstrips;
     const int sg = (u / a.nstrips) % a.nseg;
-    const int f = u / (a.nstrips * a.nseg);
-    if (a.only_frames && a.only_frames[f] == 0) return;
     const int H = a.g.H;
+    constexpr int DB = BLUR ? 2 : 0;
     int y0, y1;
     if (sg < a.nseg_top) {
         y0 = sg * a.rows_top; y1 = min(y0 + a.rows_top, a.row_split);
-        if (a.skip_top) { clear_unit<BLUR>(a, f, s, y0, y1); return; }
     } else {
         y0 = a.row_split + (sg - a.nseg_top) * a.rows_per_unit; y1 = min(y0 + a.rows_per_unit, H);
     }
-    constexpr int DB = BLUR ? 2 : 0;
     const bool hb = STRIP * s - 4 < 0 || ((a.g.W - (STRIP * s - 4)) >> 2) <= 63;
     const bool fe = y0 == 0 || y1 + DB + 1 >= H;        // rows y0 - DB - 2 .. y1 + DB + 1 are loaded
-    if (hb) {
-        if (fe) front_unit<BLUR, GATE, INTER, true, true, DEC3>(a, f, s, y0, y1);
-        else front_unit<BLUR, GATE, INTER, true, false, DEC3>(a, f, s, y0, y1);
-    } else {
-        if (fe) front_unit<BLUR, GATE, INTER, false, true, DEC3>(a, f, s, y0, y1);
-        else front_unit<BLUR, GATE, INTER, false, false, DEC3>(a, f, s, y0, y1);
+    auto unit = [&](const int f) {
+        if (sg < a.nseg_top && a.skip_top) { clear_unit<BLUR>(a, f, s, y0, y1); return; }
+        if (hb) {
+            if (fe) front_unit<BLUR, GATE, INTER, true, true, DEC3>(a, f, s, y0, y1);
+            else front_unit<BLUR, GATE, INTER, true, false, DEC3>(a, f, s, y0, y1);
+        } else {
+            if (fe) front_unit<BLUR, GATE, INTER, false, true, DEC3>(a, f, s, y0, y1);
+            else front_unit<BLUR, GATE, INTER, false, false, DEC3>(a, f, s, y0, y1);
+        }
+    };
+    // every frame: the workgroup's one frame.  Flagged frames only: this wavefront's share of the flags in one
+    // load, then frame after frame (one call site either way: the unit's code is inlined there)
+    const int j = u / (a.nstrips * a.nseg);
+    for (int base = j; base < a.nframes; base += REDO_GROUPS * 64) {
+        uint64_t todo = 1;
+        if (a.only_frames) {
+            const int fl = base + REDO_GROUPS * (int)(threadIdx.x & 63);
+            todo = __ballot(fl < a.nframes && a.only_frames[fl] != 0);
+        }
+        while (todo) {
+            const int f = base + REDO_GROUPS * __builtin_ctzll(todo);
+            todo &= todo - 1;
+            unit(f);
+        }
+        if (!a.only_frames) break;
     }
 }
 
@@ -567,7 +589,8 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
         a.rows_top = (a.row_split + a.nseg_top - 1) / a.nseg_top;
     }
     a.nseg = a.nseg_top + (g.H - a.row_split + rows_per_unit - 1) / rows_per_unit;
-    a.nunits = nframes * a.nseg * a.nstrips;
+    a.nframes = nframes;
+    a.nunits = (a.only_frames ? std::min(REDO_GROUPS, nframes) : nframes) * a.nseg * a.nstrips;
     // no LDS and no barrier: one wavefront per workgroup, so that a unit can start wherever a single wave slot
     // is free (LANECV_FRONT_WAVES overrides: waves per workgroup, 1..4)
     static const char *wv_env = getenv("LANECV_FRONT_WAVES");

@@ -288,10 +288,10 @@ __device__ __forceinline__ bool lds_mask_bit(const Ppht &c, int j, int i, uint32
 // run beside this kernel), and a job per 64 steps lets the helpers take votes back while the walker clears the
 // next chunk.  From global memory a round trip is expensive, so the general kernel takes four.
 constexpr int LINE_NC = 1, LINE_NC_GLOBAL = 4;
-#ifndef PPHT_WAVES
-#define PPHT_WAVES 8
-#endif
-constexpr int PPHT_THREADS = 64 * PPHT_WAVES, JOB_WORKERS = PPHT_WAVES - 1;   // waves: 0 consumer, 1 producer, 2.. helpers
+// Wavefronts of a fast-kernel workgroup (template parameter WAVES): 0 consumer, 1 producer, 2.. helpers; the job
+// workers are wave 0 and the helpers.  Eight when a frame has a CU to itself (the vote removal of a line is spread
+// widest); four when two frames share a CU: twice eight wavefronts of 72 registers leave a SIMD room for two of
+// the edge kernel's wavefronts instead of four, and everything beside HoughLinesP crawls.
 struct Jobs {
     int seq;                     // jobs posted so far; -1 tells the helpers to leave
     int done;                    // workers that finished job `seq`
@@ -324,7 +324,9 @@ __device__ __forceinline__ void vote_bin(const VoteLane &vl, float fj, float fi,
     widx = a >> 1;
 }
 
+template <int WAVES>
 __device__ __forceinline__ void job_work(Jobs *jb, int part, const VoteLane &vl, int lane) {
+    constexpr int JOB_WORKERS = WAVES - 1;
     Walk wk;
     wk.xflag = __builtin_amdgcn_readfirstlane(jb->par[0]); wk.x0 = __builtin_amdgcn_readfirstlane(jb->par[1]);
     wk.y0 = __builtin_amdgcn_readfirstlane(jb->par[2]); wk.dx = __builtin_amdgcn_readfirstlane(jb->par[3]);
@@ -354,14 +356,17 @@ __device__ __forceinline__ void job_work(Jobs *jb, int part, const VoteLane &vl,
 }
 
 // wave 0: do its share of the job in flight (if any) and wait for the helpers
+template <int WAVES>
 __device__ __forceinline__ void job_finish(Jobs *jb, bool inflight, const VoteLane &vl, int lane) {
+    constexpr int JOB_WORKERS = WAVES - 1;
     if (!inflight) return;
-    job_work(jb, 0, vl, lane);
+    job_work<WAVES>(jb, 0, vl, lane);
     while (*(volatile int *)&jb->done < JOB_WORKERS) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // helper wavefronts (parts 1 .. JOB_WORKERS - 1): serve every job until told to leave
+template <int WAVES>
 __device__ __forceinline__ void job_serve(Jobs *jb, int part, const VoteLane &vl, int lane) {
     int seen = 0;
     for (;;) {
@@ -370,7 +375,7 @@ __device__ __forceinline__ void job_serve(Jobs *jb, int part, const VoteLane &vl
         if (sq < 0) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         seen = sq;
-        job_work(jb, part, vl, lane);
+        job_work<WAVES>(jb, part, vl, lane);
     }
 }
 
@@ -453,7 +458,7 @@ struct LineOut {
 // constants stay in registers.)
 // Returns (accepted ? 1 : 0) | jobs posted so far << 1 (segment number nseg is written if it fits).
 // jobseq is the caller's count of vote-removal jobs posted so far; it lives in registers, not LDS.
-template <bool LDS_STATE>
+template <bool LDS_STATE, int WAVES = 8>
 __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int i, int max_n, int nseg, Jobs *jb, int jobseq,
                                             const VoteLane &vl, LineOut &lo) {
     constexpr int NC = LDS_STATE ? LINE_NC : LINE_NC_GLOBAL;
@@ -596,7 +601,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
             }
         if constexpr (LDS_STATE) {
             if (good && any) {   // hand the stretch's vote removal to the workgroup
-                job_finish(jb, inflight, vl, lane);       // one job in flight at a time
+                job_finish<WAVES>(jb, inflight, vl, lane);       // one job in flight at a time
                 ++jobseq;
                 if (lane == 0) {
                     jb->par[0] = wk.xflag; jb->par[1] = wk.x0; jb->par[2] = wk.y0; jb->par[3] = wk.dx; jb->par[4] = wk.dy;
@@ -619,7 +624,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
 #ifdef LC_STAMPS
     long long ts2 = STAMP();
 #endif
-    if constexpr (LDS_STATE) job_finish(jb, inflight, vl, lane);   // every vote is back before the next pick
+    if constexpr (LDS_STATE) job_finish<WAVES>(jb, inflight, vl, lane);   // every vote is back before the next pick
 #ifdef LC_STAMPS
     long long ts3 = STAMP();
 #endif
@@ -638,17 +643,14 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
 
 // General path: every piece of state in global memory behind agent-scope atomics, any number of
 // angles and points.  After the fast path it only runs the frames that path flagged.
-__global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restrict__ nz_all, int nz_cap,
+__device__ __forceinline__ void ppht_general_frame(const int f, const int fl, int *lacc_vote, Geo g, uint32_t *__restrict__ nz_all, int nz_cap,
                                                       const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
                                                       const AngleEntry *__restrict__ tab, int numangle, int numrho,
                                                       int32_t *__restrict__ acc_all, int threshold, int line_length,
                                                       int line_gap, int32_t *__restrict__ seg_all, int seg_cap,
                                                       int *__restrict__ seg_count, int *__restrict__ status,
-                                                      const int *__restrict__ fallback, int32_t *__restrict__ vote_acc,
-                                                      int vote_apg) {
-    extern __shared__ int lacc_vote[];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int fl = fallback ? fallback[f] : 3;
+                                                      int32_t *__restrict__ vote_acc, int vote_apg) {
+    const int tid = threadIdx.x, lane = tid & 63;
     // the full-vote accumulator of a frame the fast kernel could not do, before this kernel permutes the point list
     if (vote_acc && (fl & 2)) vote_frame(lacc_vote, f, 0, 1, nz_all, nz_cap, npoints, tab, numangle, numrho, vote_apg, vote_acc);
     if (!(fl & 1)) return;
@@ -705,13 +707,45 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, uint32_t *__restric
     if (lane == 0) seg_count[f] = nseg;
 }
 
+// One workgroup per frame when every frame is to be done (flags null); otherwise a few workgroups that look up which
+// frames the fast kernel flagged -- a wavefront's share of the flags in one load -- and do those one after the other.
+// Nearly always none is flagged, and a workgroup per frame that only reads its flag still has to find a place on a
+// GPU that the other kernels keep full.
+__global__ __launch_bounds__(256) void k_ppht_general(Geo g, int nframes, uint32_t *__restrict__ nz_all, int nz_cap,
+                                                      const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
+                                                      const AngleEntry *__restrict__ tab, int numangle, int numrho,
+                                                      int32_t *__restrict__ acc_all, int threshold, int line_length,
+                                                      int line_gap, int32_t *__restrict__ seg_all, int seg_cap,
+                                                      int *__restrict__ seg_count, int *__restrict__ status,
+                                                      const int *__restrict__ fallback, int32_t *__restrict__ vote_acc,
+                                                      int vote_apg) {
+    extern __shared__ int lacc_vote[];
+    const int G = gridDim.x;
+    for (int base = blockIdx.x; base < nframes; base += G * 64) {
+        uint64_t todo = 1;
+        if (fallback) {
+            const int fi = base + G * (int)(threadIdx.x & 63);
+            todo = __ballot(fi < nframes && (fallback[fi] & 3) != 0);
+        }
+        while (todo) {
+            const int f = base + G * __builtin_ctzll(todo);
+            todo &= todo - 1;
+            ppht_general_frame(f, fallback ? fallback[f] : 3, lacc_vote, g, nz_all, nz_cap, npoints, rowplane, tab, numangle, numrho,
+                               acc_all, threshold, line_length, line_gap, seg_all, seg_cap, seg_count, status, vote_acc, vote_apg);
+            __syncthreads();
+        }
+        if (!fallback) break;
+    }
+}
+
 // Fast path (up to 64 angles, point list and int16 accumulator fit the CU's LDS):
 //   wavefront 1 runs the data-independent part of OpenCV's loop -- the MWC random picks with
 //   swap-remove -- ahead of time, leaving the visiting order in the point array itself (the removed
 //   point goes to the slot the swap frees, so the array read from the back is the order);
 //   wavefront 0 follows it, with the mask words of the next four points in flight, votes in LDS with
 //   one angle per lane and reduces the maximum with DPP.
-__global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_t *__restrict__ nz_all, int nz_cap,
+template <int PPHT_WAVES>
+__global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint32_t *__restrict__ nz_all, int nz_cap,
                                                    const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
                                                    const AngleEntry *__restrict__ tab, int numangle, int numrho,
                                                    int threshold, int line_length, int line_gap,
@@ -719,6 +753,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
                                                    int *__restrict__ status, int *__restrict__ fallback, int lds_points,
                                                    const uint32_t *__restrict__ rng_out, int lds_bytes,
                                                    int32_t *__restrict__ acc_full, int only_flagged) {
+    constexpr int PPHT_THREADS = 64 * PPHT_WAVES;
     extern __shared__ __align__(16) uint32_t lds32[];
     __shared__ int progress;
     __shared__ Jobs jobs;
@@ -915,7 +950,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
     }
     __syncthreads();
     if (wave >= 2) {                // helpers: vote removal for accepted lines
-        job_serve(&jobs, wave - 1, vl, lane);
+        job_serve<PPHT_WAVES>(&jobs, wave - 1, vl, lane);
         return;
     }
 
@@ -1064,7 +1099,7 @@ __global__ __launch_bounds__(PPHT_THREADS) void k_ppht_fast(Geo g, const uint32_
                 n_line++;
 #endif
                 LineOut lo;
-                const int lr = extract_line<true>(c, lane, (int)(hpt & 0xFFFF), (int)(hpt >> 16), max_n, nseg, &jobs, jobseq, vl, lo);
+                const int lr = extract_line<true, PPHT_WAVES>(c, lane, (int)(hpt & 0xFFFF), (int)(hpt >> 16), max_n, nseg, &jobs, jobseq, vl, lo);
                 jobseq = lr >> 1;
                 if (lr & 1) nseg++;
                 // which points of the batch the line took: signed step of the lane's point along the major axis
@@ -1155,11 +1190,20 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
     if (lds_bytes <= 0 || lds_bytes > PPHT_LDS_MAX) lds_bytes = PPHT_LDS_MAX;
     const int lds_points = std::min(rng_len, LDS_BIAS - 1);
-    static LdsOptIn optin;
-    if (optin.ensure(reinterpret_cast<const void *>(k_ppht_fast), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
-    hipLaunchKernelGGL(k_ppht_fast, dim3(nframes), dim3(PPHT_THREADS), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
-                       numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                       lds_bytes, acc_full, only_flagged ? 1 : 0);
+    static LdsOptIn optin8, optin4;
+    static const char *wv_env = getenv("LANECV_PPHT_WAVES");           // diagnostics: 4 or 8 whatever the LDS size
+    const bool four = wv_env ? wv_env[0] == '4' : lds_bytes <= PPHT_LDS_HALF;
+    if (four) {
+        if (optin4.ensure(reinterpret_cast<const void *>(k_ppht_fast<4>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
+        hipLaunchKernelGGL(k_ppht_fast<4>, dim3(nframes), dim3(256), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+                           numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
+                           lds_bytes, acc_full, only_flagged ? 1 : 0);
+    } else {
+        if (optin8.ensure(reinterpret_cast<const void *>(k_ppht_fast<8>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
+        hipLaunchKernelGGL(k_ppht_fast<8>, dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+                           numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
+                           lds_bytes, acc_full, only_flagged ? 1 : 0);
+    }
     return true;
 }
 
@@ -1175,8 +1219,9 @@ void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int
         static LdsOptIn optin;
         (void)optin.ensure(reinterpret_cast<const void *>(k_ppht_general), lds);
     }
-    hipLaunchKernelGGL(k_ppht_general, dim3(nframes), dim3(256), lds, st, g, nz, nz_cap, npoints, rowplane, tab, numangle, numrho,
-                       acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, vote_acc, apg);
+    hipLaunchKernelGGL(k_ppht_general, dim3(flags ? std::min(nframes, 16) : nframes), dim3(256), lds, st, g, nframes, nz, nz_cap, npoints,
+                       rowplane, tab, numangle, numrho, acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags,
+                       vote_acc, apg);
 }
 
 #ifdef LC_STAMPS
