@@ -1170,6 +1170,13 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     if (!points) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
                     w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p);
+    if (pp->row_split > 0) {
+        // frames that were classified in full: their plane rows above the split are cleared again, now that they
+        // have been read (a few workgroups that look at the flags and, nearly always, leave)
+        const FrontSplit clear{pp->row_split, 2, w.redo.p};
+        launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
+                     nullptr, nullptr, es, nullptr, nullptr, nullptr, w.rowflags.p, pp->fused_dec3(), pp->front_rows, &clear);
+    }
     (void)hipEventRecord(s.ev[EV_EDGE], es);
     if (points) launch_points(w.g, n, w.rowplane.p, w.rowcount.p, w.nz.p, w.nz_cap, w.npoints.p, w.r_status, es);
     (void)hipEventRecord(s.ev[EV_POINTS], es);
@@ -1331,7 +1338,6 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     pp->line_length = (int)lrint(p.min_line_length);
     pp->line_gap = (int)lrint(p.max_line_gap);
     if (const char *fv = getenv("LANECV_VOTE_FUSED")) pp->fuse_vote = fv[0] != '0';
-    pp->front_rows = front_stream_rows_per_unit(pp->g, p.max_batch);
     pp->ppht_two_per_cu = p.want_segments && (size_t)p.width * p.height <= 2600000 && p.nslots >= 3;
     if (const char *tp = getenv("LANECV_PPHT_TWO_PER_CU")) pp->ppht_two_per_cu = tp[0] != '0';   // diagnostics
 
@@ -1397,6 +1403,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         if (pp->has_roi && !p.keep_intermediates && front_stream_supported(pp->g) && !getenv("LANECV_FRONT_TILED") && !ns &&
             pp->roi_first_row - BAND >= 64)
             pp->row_split = pp->roi_first_row - BAND;
+        pp->front_rows = front_stream_rows_per_unit(pp->g, p.max_batch, p.height - pp->row_split);
     }
     {
         // All streams have the same priority.  With the post and HoughLinesP streams at high priority their few

@@ -77,17 +77,17 @@ void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_
 // streaming front kernel (kernels_front_stream.hip): interleaved 3-channel input, W % 4 == 0
 bool front_stream_supported(Geo g);
 int front_stream_strips(Geo g);     // 248-column strips per frame row
-int front_stream_rows_per_unit(Geo g, int max_batch);
+int front_stream_rows_per_unit(Geo g, int max_batch, int rows_classified);   // rows_classified: 0 = all of them
 // Rows the final edge map cannot depend on need not be classified.  With an ROI whose first row is far down the frame, a
-// pipeline splits the frame at row_split: a launch with skip_top classifies rows >= row_split only (the units above
-// only clear what a full pass left behind); launch_band_check then decides per frame whether that was enough, and a
-// second launch without skip_top and with only_frames redoes the frames for which it was not.
+// pipeline splits the frame at row_split: a launch in mode 1 classifies rows >= row_split only; launch_band_check then
+// decides per frame whether that was enough; a launch in mode 0 with only_frames redoes the frames for which it was not,
+// from row 0; and once their planes have been consumed a launch in mode 2 (with the same flags) clears the plane rows
+// above row_split that the full pass stored, so that the next batch finds them empty again.
 struct FrontSplit {
     int row_split;              // > 0: first row of the lower region
-    int skip_top;               // 1: do not classify rows above row_split
+    int mode;                   // 0: all rows; 1: rows >= row_split only; 2: clear the plane rows above row_split
     const int *only_frames;     // device flags, one per frame, or null: frames whose flag is 0 are left alone
 };
-// gate (may be null): the colour gate applied to the frame before the gray conversion; tab as above
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                          int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags = nullptr,

@@ -144,9 +144,10 @@ struct FrontArgs {
     uint32_t *wake;          // per 64x64 tile: set where a weak pixel is stored (the hysteresis kernel's work list)
     uint8_t *rowflags;       // [frame][strip][row]: the plane bytes last stored for that strip row were not all zero; or null
     int rows_per_unit, nseg, nstrips, nunits;
-    // rows [0, row_split) form a region of their own with nseg_top units of rows_top rows (0: no such region).
-    // skip_top: those units only clear what an earlier full pass left in their plane rows (see FrontSplit).
-    int row_split, nseg_top, rows_top, skip_top;
+    // rows [0, row_split) form a region of their own with nseg_top units of rows_top rows (0: no such region); the
+    // launch covers the units seg_first .. seg_first + nseg - 1 of a frame's nseg_top + lower units.  clear_top: the
+    // launch only clears what a full pass left in the plane rows of the top region (see FrontSplit).
+    int row_split, nseg_top, rows_top, seg_first, clear_top;
     // if set: only the frames whose word is non-zero are done, and the grid is not one workgroup per unit of every
     // frame but REDO_GROUPS per unit of ONE frame (nearly always no frame is flagged: 20 000 workgroups that only
     // look at a flag would cost more than the check is worth); group j does the flagged frames j, j + GROUPS, ...
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const int u = __builtin_amdgcn_readfirstlane(wgl * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // wave-uniform
     if (u >= a.nunits) return;
     const int s = u % a.nstrips;
-    const int sg = (u / a.nstrips) % a.nseg;
+    const int sg = a.seg_first + (u / a.nstrips) % a.nseg;
     const int H = a.g.H;
     constexpr int DB = BLUR ? 2 : 0;
     int y0, y1;
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const bool hb = STRIP * s - 4 < 0 || ((a.g.W - (STRIP * s - 4)) >> 2) <= 63;
     const bool fe = y0 == 0 || y1 + DB + 1 >= H;        // rows y0 - DB - 2 .. y1 + DB + 1 are loaded
     auto unit = [&](const int f) {
-        if (sg < a.nseg_top && a.skip_top) { clear_unit<BLUR>(a, f, s, y0, y1); return; }
+        if (a.clear_top) { clear_unit<BLUR>(a, f, s, y0, y1); return; }
         if (hb) {
             if (fe) front_unit<BLUR, GATE, INTER, true, true, DEC3>(a, f, s, y0, y1);
             else front_unit<BLUR, GATE, INTER, true, false, DEC3>(a, f, s, y0, y1);
@@ -552,11 +553,12 @@ int front_stream_strips(Geo g) { return (TILE * g.TX + STRIP - 1) / STRIP; }
 // rows per unit of the streaming kernel for batches of up to `max_batch` frames: enough units to load every CU many
 // times over (80 per CU measured best beside HoughLinesP: finer units balance better around its resident workgroups),
 // few enough to keep the 8 halo rows cheap.  A pipeline fixes it once: the kernel's change tracking is kept per unit.
-int front_stream_rows_per_unit(Geo g, int max_batch) {
+int front_stream_rows_per_unit(Geo g, int max_batch, int rows_classified) {
     const int nstrips = front_stream_strips(g);
     int want = 20480 / (max_batch * nstrips > 0 ? max_batch * nstrips : 1);
     if (want < 1) want = 1;
-    int rows = (g.H + want - 1) / want;
+    if (rows_classified <= 0 || rows_classified > g.H) rows_classified = g.H;
+    int rows = (rows_classified + want - 1) / want;
     if (rows < 64) rows = 64;
     return rows > g.H ? g.H : rows;
 }
@@ -577,18 +579,24 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.k_lo = (k0 & 255) | ((k1 & 255) << 8) | ((k2 & 255) << 16);
     a.k_hi = (k0 >> 8) | ((k1 >> 8) << 8) | ((k2 >> 8) << 16);
     a.nstrips = front_stream_strips(g);              // every byte of every plane row is covered
-    if (rows_per_unit <= 0) rows_per_unit = front_stream_rows_per_unit(g, nframes);
+    if (rows_per_unit <= 0) rows_per_unit = front_stream_rows_per_unit(g, nframes, 0);
     if (rows_per_unit > g.H) rows_per_unit = g.H;
     a.rows_per_unit = rows_per_unit;
     a.row_split = split ? split->row_split : 0;
-    a.skip_top = split ? split->skip_top : 0;
     a.only_frames = split ? split->only_frames : nullptr;
-    a.nseg_top = a.rows_top = 0;
-    if (a.row_split > 0) {                           // the top region in units of about the same height
+    a.nseg_top = a.rows_top = a.seg_first = a.clear_top = 0;
+    const int rows_low = g.H - a.row_split;
+    int nseg_low = (rows_low + rows_per_unit - 1) / rows_per_unit;
+    if (a.row_split > 0) {                           // both regions in units of about the same height
         a.nseg_top = (a.row_split + rows_per_unit - 1) / rows_per_unit;
         a.rows_top = (a.row_split + a.nseg_top - 1) / a.nseg_top;
+        a.rows_per_unit = (rows_low + nseg_low - 1) / nseg_low;
+        nseg_low = (rows_low + a.rows_per_unit - 1) / a.rows_per_unit;
     }
-    a.nseg = a.nseg_top + (g.H - a.row_split + rows_per_unit - 1) / rows_per_unit;
+    a.nseg = a.nseg_top + nseg_low;
+    if (split && split->mode == 1) { a.seg_first = a.nseg_top; a.nseg = nseg_low; }
+    if (split && split->mode == 2) { a.nseg = a.nseg_top; a.clear_top = 1; }
+    if (a.nseg == 0) return;
     a.nframes = nframes;
     a.nunits = (a.only_frames ? std::min(REDO_GROUPS, nframes) : nframes) * a.nseg * a.nstrips;
     // no LDS and no barrier: one wavefront per workgroup, so that a unit can start wherever a single wave slot
