@@ -52,11 +52,11 @@ def make_frames(seed, n, workers):
 def pmc_traffic(batch):
     """HBM bytes per k_front_stream launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
     WRITE_SIZE runs, FETCH_SIZE doubled as gfx950 needs); None when the launch shape differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "round1_v10_pmc_edge_stage.json")
+    path = os.path.join(ROOT, "profiles", "round2_pmc_edge_stage.json")
     if batch != 256 or not os.path.exists(path):
         return None
     with open(path) as fh:
-        return round(json.load(fh)["kernels"]["k_front_stream<true, 0, false>"]["traffic_bytes"])
+        return round(json.load(fh)["kernels"]["k_front_stream<true, 0, false, false>"]["traffic_bytes"])
 
 
 def vote_rates(dev_ptr, batch, device):
@@ -303,7 +303,7 @@ def main():
                        "width": W, "height": H, "batch": batch, "slots_in_flight": args.slots,
                        "sharding": "clip-major (clip c on GPU c mod N), no data-path collective, one final unpadded segment gather",
                        "clips": nclips_total, "frames_per_clip": frames_per_clip},
-            "roofline": {"bound": "hbm", "kernel": "k_front_stream<true, 0, false>",
+            "roofline": {"bound": "hbm", "kernel": "k_front_stream<true, 0, false, false>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(batch),
                          "algorithmic_bytes_per_launch": front_bytes, "launch_ms": round(front_ms, 4),
@@ -336,7 +336,7 @@ def main():
                                       "algorithmic_bytes_per_launch": stage_bytes, "launch_ms": round(edge_x, 4),
                                       "achieved": round(stage_bytes / (edge_x * 1e-3) / 1e9, 1),
                                       "frac": round(stage_bytes / (edge_x * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        out["roofline_exclusive"] = {"kernel": "k_front_stream<true, 0, false>, nothing else on the GPU", "launch_ms": round(em["front"], 4),
+        out["roofline_exclusive"] = {"kernel": "k_front_stream<true, 0, false, false>, nothing else on the GPU", "launch_ms": round(em["front"], 4),
                                      "achieved": round(front_bytes / (em["front"] * 1e-3) / 1e9, 1),
                                      "frac": round(front_bytes / (em["front"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "stage_ms": {k: round(v, 4) for k, v in em.items()}}

@@ -497,8 +497,10 @@ __device__ __forceinline__ void clear_unit(const FrontArgs &a, const int f, cons
     }
 }
 
-template <bool BLUR, int GATE, bool INTER, bool DEC3 = false>
-__global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
+// The kernel proper.  (k_front_again is the same code under a name of its own: the launch that classifies flagged
+// frames a second time, so that profiles tell the two apart.)
+template <bool BLUR, int GATE, bool INTER, bool DEC3>
+__device__ __forceinline__ void front_stream_body(const FrontArgs &a) {
     // Workgroups go round-robin over the 8 XCDs, each with its own L2.  Neighbouring strips share the cache lines
     // their rows meet in (a strip row is 744 bytes, not a multiple of 128) and the plane bytes they write, so
     // consecutive units are handed to ONE XCD: workgroup b works on logical workgroup (b % 8) * chunk + b / 8.
@@ -518,7 +520,6 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
     const bool hb = STRIP * s - 4 < 0 || ((a.g.W - (STRIP * s - 4)) >> 2) <= 63;
     const bool fe = y0 == 0 || y1 + DB + 1 >= H;        // rows y0 - DB - 2 .. y1 + DB + 1 are loaded
     auto unit = [&](const int f) {
-        if (a.clear_top) { clear_unit<BLUR>(a, f, s, y0, y1); return; }
         if (hb) {
             if (fe) front_unit<BLUR, GATE, INTER, true, true, DEC3>(a, f, s, y0, y1);
             else front_unit<BLUR, GATE, INTER, true, false, DEC3>(a, f, s, y0, y1);
@@ -542,6 +543,29 @@ __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) {
             unit(f);
         }
         if (!a.only_frames) break;
+    }
+}
+
+template <bool BLUR, int GATE, bool INTER, bool DEC3 = false>
+__global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) { front_stream_body<BLUR, GATE, INTER, DEC3>(a); }
+template <bool BLUR, int GATE, bool DEC3>
+__global__ __launch_bounds__(256) void k_front_again(FrontArgs a) { front_stream_body<BLUR, GATE, false, DEC3>(a); }
+
+// clears, for the flagged frames, the plane rows above row_split that a full pass stored (FrontSplit mode 2)
+template <bool BLUR>
+__global__ __launch_bounds__(256) void k_front_clear(FrontArgs a) {
+    const int wgl = (int)(blockIdx.x & 7u) * a.wg_chunk + (int)(blockIdx.x >> 3);
+    const int u = __builtin_amdgcn_readfirstlane(wgl * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+    if (u >= a.nunits) return;
+    const int s = u % a.nstrips, sg = (u / a.nstrips) % a.nseg, j = u / (a.nstrips * a.nseg);
+    const int y0 = sg * a.rows_top, y1 = min(y0 + a.rows_top, a.row_split);
+    for (int base = j; base < a.nframes; base += REDO_GROUPS * 64) {
+        const int fl = base + REDO_GROUPS * (int)(threadIdx.x & 63);
+        uint64_t todo = __ballot(fl < a.nframes && a.only_frames[fl] != 0);
+        while (todo) {
+            clear_unit<BLUR>(a, base + REDO_GROUPS * __builtin_ctzll(todo), s, y0, y1);
+            todo &= todo - 1;
+        }
     }
 }
 
@@ -608,6 +632,20 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.wg_chunk = (nwg + 7) / 8;
     dim3 grid(8 * a.wg_chunk), block(64 * wpg);
     const bool inter = gray_out || blur_out;
+    if (a.clear_top) {
+        if (!a.only_frames || !a.rowflags) return;
+        if (blur) hipLaunchKernelGGL((k_front_clear<true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_front_clear<false>), grid, block, 0, st, a);
+        return;
+    }
+    if (a.only_frames) {      // the second pass over flagged frames (never with intermediates)
+#define LC_FA(B, G, D) hipLaunchKernelGGL((k_front_again<B, G, D>), grid, block, 0, st, a)
+        if (dec3) { if (blur) LC_FA(true, 0, true); else LC_FA(false, 0, true); }
+        else if (gate) { if (blur) LC_FA(true, 1, false); else LC_FA(false, 1, false); }
+        else { if (blur) LC_FA(true, 0, false); else LC_FA(false, 0, false); }
+#undef LC_FA
+        return;
+    }
 #define LC_FS(B, G, I) hipLaunchKernelGGL((k_front_stream<B, G, I>), grid, block, 0, st, a)
 #define LC_FS2(B, G) do { if (inter) LC_FS(B, G, true); else LC_FS(B, G, false); } while (0)
     if (dec3) {   // src holds frames of 3 W x 3 H (the caller checked: no gate, no intermediates)
