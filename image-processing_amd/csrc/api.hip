@@ -1143,6 +1143,7 @@ struct lc_pipe {
     // `ppht_full_for` batches get a whole CU's LDS per frame again, after which the half size is tried anew.
     bool ppht_two_per_cu = false;
     int ppht_full_for = 0;
+    int cu_count = 256;
     int shared_queues = 0;        // streams of this layout that found no hardware queue of their own (lc_pipe_create)
 
     // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs).  The HoughLinesP
@@ -1210,7 +1211,8 @@ void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
         const bool fast = launch_ppht_fast(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
                                            p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
                                            w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls,
-                                           (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false);
+                                           (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false,
+                                           2 * p.max_batch > pp->cu_count ? 0 : 8);
         if (pp->ppht_full_for > 0) pp->ppht_full_for--;
         // one launch for the frames the fast kernel flagged: their full-vote accumulator first (the general kernel
         // permutes the point list), then HoughLinesP with all state in global memory.  No events in between: every
@@ -1453,8 +1455,9 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
         if (own_lines) {
             hipDeviceProp_t prop;
             int want = 1;
-            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
-                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * prop.multiProcessorCount / p.max_batch, p.nslots - 1), 3));
+            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) pp->cu_count = prop.multiProcessorCount;
+            if (pp->cu_count > 0)
+                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * pp->cu_count / p.max_batch, p.nslots - 1), 3));
             const char *ns = getenv("LANECV_LINES_STREAMS");
             if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
             for (int k = 1; k < want; k++) {

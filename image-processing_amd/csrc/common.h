@@ -164,7 +164,9 @@ int lds_atomic_probe(int run, bool returning, int blocks, int iters, int *sink, 
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
-                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes = 0, bool only_flagged = false);
+                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes = 0, bool only_flagged = false, int waves = 0);
+// waves: 8 or 4 wavefronts per frame (0: 4 with ppht_lds_half(), else 8).  Four is for launches that fill every CU twice
+// over; a batch that leaves CUs free is better served by eight even with half the LDS.
 // lds_bytes: dynamic LDS per frame (0 = the most a CU gives one workgroup); with ppht_lds_half() two frames share a
 // CU, and a second launch with only_flagged and the full size takes the frames that needed more
 int ppht_lds_half();

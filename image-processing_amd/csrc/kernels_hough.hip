@@ -1184,7 +1184,7 @@ int ppht_lds_half() { return PPHT_LDS_HALF; }
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
-                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged) {
+                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged, int waves) {
     // points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not fit lds_bytes (the
     // kernel decides, per frame) is flagged.
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
@@ -1192,7 +1192,7 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
     const int lds_points = std::min(rng_len, LDS_BIAS - 1);
     static LdsOptIn optin8, optin4;
     static const char *wv_env = getenv("LANECV_PPHT_WAVES");           // diagnostics: 4 or 8 whatever the LDS size
-    const bool four = wv_env ? wv_env[0] == '4' : lds_bytes <= PPHT_LDS_HALF;
+    const bool four = wv_env ? wv_env[0] == '4' : (waves ? waves == 4 : lds_bytes <= PPHT_LDS_HALF);
     if (four) {
         if (optin4.ensure(reinterpret_cast<const void *>(k_ppht_fast<4>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
         hipLaunchKernelGGL(k_ppht_fast<4>, dim3(nframes), dim3(256), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
