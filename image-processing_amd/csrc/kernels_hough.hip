@@ -232,8 +232,13 @@ struct Walk {
 __device__ long long g_stamps[8];   // diagnostic build only: cycle sums of frame 0
 __device__ unsigned long long g_dbg[4];
 __device__ int g_simd[8];
+__device__ long long g_setup[16];             // frame 0: cycles since kernel start at the marks of the set-up
+#define SETUP_MARK(k) do { if (f == 0 && tid == 0) g_setup[k] = STAMP() - t_kernel0; } while (0)
 __device__ long long g_frame_cycles[1024];   // consumer loop and whole kernel (set-up included) per frame: [2f], [2f + 1]
 #define STAMP() __builtin_amdgcn_s_memtime()
+#endif
+#ifndef LC_STAMPS
+#define SETUP_MARK(k) do { } while (0)
 #endif
 #ifndef PPHT_Q
 #define PPHT_Q 4   // points voting speculatively per group in the LDS path
@@ -827,6 +832,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         if (lane == 0) { atomicMin(&s_xmin, xmin); atomicMax(&s_xmax, xmax); }
     }
     __syncthreads();
+    SETUP_MARK(0);
     for (int i = tid; i < n; i += PPHT_THREADS) {
         // the first point of every 64-pixel word marks the word in its row's map
         const uint32_t pt = lnz[i];
@@ -836,6 +842,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
             atomicOr(&rowtab[4 * (y - ymin) + 2 + (wi >> 5)], 1u << (wi & 31));
     }
     __syncthreads();
+    SETUP_MARK(1);
     {   // exclusive scan of the kept-word counts over the rows -> LDS index of every row's first word
         const int per = (nrows + PPHT_THREADS - 1) / PPHT_THREADS;
         const int r0 = tid * per, r1 = min(nrows, r0 + per);
@@ -856,6 +863,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         }
         if (tid == PPHT_THREADS - 1) s_maskwords = s_part[tid];
     }
+    SETUP_MARK(2);
     if (wave == 0) {   // reachable bins of every angle: the extremes are at the corners of the bounding box
         const int xmin = s_xmin, xmax = s_xmax;
         float ac = 0.f, as = 0.f;
@@ -908,6 +916,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     vl.rfix = a_rfix[lane];
     vl.wid = a_wid[lane];
     vl.words = reinterpret_cast<uint32_t *>(c.lacc);
+    SETUP_MARK(3);
     if (acc_full != nullptr) {
         uint32_t *fw = vl.words;
         for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) fw[i] = 0;
@@ -916,7 +925,23 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
             const int m = min(64, n - p0);
             const uint32_t ptv = lane < m ? lnz[p0 + lane] : 0u;
             const float fjv = (float)(ptv & 0xFFFF), fiv = (float)(ptv >> 16);
-            for (int t = 0; t < m; t++) {
+            // four points at a time as straight-line code (coordinates out of the lanes first, then the four bins, then
+            // the four adds): one point per iteration left the wavefront waiting on every step of its own chain
+            int t = 0;
+            for (; t + 4 <= m; t += 4) {
+                float fj[4], fi[4];
+                uint32_t widx[4], sh[4], over;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    fj[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), t + q));
+                    fi[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), t + q));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) vote_bin(vl, fj[q], fi[q], widx[q], sh[q], over);
+#pragma unroll
+                for (int q = 0; q < 4; q++) atomicAdd(&fw[widx[q]], vl.one << sh[q]);
+            }
+            for (; t < m; t++) {
                 const float fj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), t));
                 const float fi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), t));
                 uint32_t widx, sh, over;
@@ -925,6 +950,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
             }
         }
         __syncthreads();
+        SETUP_MARK(4);
         // write-out in OpenCV's [angle][rho] shape: zeros outside the reachable range of an angle
         for (int a = wave; a < numangle; a += PPHT_WAVES) {
             const int rmin = a_rmin[a], wid = (int)a_wid[a];
@@ -942,13 +968,41 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         }
         __syncthreads();
     }
+    SETUP_MARK(5);
     for (int i = tid; i < (int)acc_words; i += PPHT_THREADS) lds32[acc_off + i] = (uint32_t)LDS_BIAS * 0x10001u;
-    for (int r = wave; r < nrows; r += PPHT_THREADS / 64) {     // lane = image word of the row
-        const uint4 e = c.rowtab[r];
-        uint32_t widx;
-        if (row_word(e, lane, widx)) c.lmask[widx] = c.mask[(size_t)(ymin + r) * c.TX + lane];
+    // the kept mask words: the first point of every 64-pixel word fetches the word.  Four points per thread at a time,
+    // address arithmetic first, then the loads together, then the stores: one round trip to memory per four words,
+    // not one per word (a loop over the rows, a row per wavefront, spent a quarter of the set-up waiting for them).
+    for (int i0 = tid; i0 < n; i0 += 4 * PPHT_THREADS) {
+        uint32_t widx[4];
+        const uint64_t *src[4];
+        bool first[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + k * PPHT_THREADS;
+            first[k] = false;
+            widx[k] = 0;
+            src[k] = c.mask;
+            if (i < n) {
+                const uint32_t pt = lnz[i];
+                const int wi = (int)(pt & 0xFFFF) >> 6, y = (int)(pt >> 16);
+                const uint32_t pv = i ? lnz[i - 1] : 0u;
+                first[k] = i == 0 || (int)(pv >> 16) != y || ((int)(pv & 0xFFFF) >> 6) != wi;
+                if (first[k]) {
+                    (void)row_word(c.rowtab[y - ymin], wi, widx[k]);
+                    src[k] = c.mask + (size_t)y * c.TX + wi;
+                }
+            }
+        }
+        uint64_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = first[k] ? *src[k] : 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (first[k]) c.lmask[widx[k]] = w[k];
     }
     __syncthreads();
+    SETUP_MARK(6);
     if (wave >= 2) {                // helpers: vote removal for accepted lines
         job_serve<PPHT_WAVES>(&jobs, wave - 1, vl, lane);
         return;
@@ -1230,6 +1284,7 @@ extern "C" int lc_debug_stamps(long long *out) {
     (void)hipMemcpyFromSymbol(out + 12, HIP_SYMBOL(g_simd), sizeof(int) * 8);
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 8);
 }
+extern "C" int lc_debug_setup(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup), sizeof(long long) * 16); }
 extern "C" int lc_debug_frame_cycles(long long *out, int nframes) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_frame_cycles), sizeof(long long) * 2 * (nframes < 512 ? nframes : 512));
 }

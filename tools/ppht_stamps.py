@@ -23,3 +23,7 @@ a = np.array(list(fc), dtype=np.int64).reshape(B, 2)
 for name, col in (("consumer loop", a[:, 0]), ("whole kernel", a[:, 1])):
     print(name, "cycles per frame: min %d  median %d  mean %d  max %d" % (col.min(), np.median(col), col.mean(), col.max()))
 print("slowest frames", np.argsort(a[:, 1])[-5:], "set-up (kernel - loop) median", int(np.median(a[:, 1] - a[:, 0])))
+su = (C.c_longlong * 16)()
+if hasattr(_abi.lib(), "lc_debug_setup"):
+    _abi.lib().lc_debug_setup(su)
+    print("set-up marks of frame 0 (cycles since kernel start): points copied, words marked, scanned, ranges, before vote / after vote / after write-out / masks in:", list(su)[:7])
