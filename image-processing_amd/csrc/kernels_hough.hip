@@ -346,14 +346,21 @@ __device__ __forceinline__ void job_work(Jobs *jb, int part, const VoteLane &vl,
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb->bits[k][q][0]);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb->bits[k][q][1]);
             uint64_t m = (((uint64_t)hi << 32) | lo) & pat;
+            // two pixels at a time as straight-line code: positions first, then the bins, then the subtractions
             while (m) {
-                const int t = base + q * 64 + __builtin_ctzll(m);
+                const int t0 = base + q * 64 + __builtin_ctzll(m);
                 m &= m - 1;
-                int j1, i1;
-                wk.at(t, k ? -1 : 1, j1, i1);
-                uint32_t widx, sh, over;
-                vote_bin(vl, (float)j1, (float)i1, widx, sh, over);
-                atomicSub(&vl.words[widx], vl.one << sh);
+                const bool two = m != 0;
+                const int t1 = two ? base + q * 64 + __builtin_ctzll(m) : t0;
+                m &= m - 1;          // (0 & anything stays 0)
+                int j0, i0, j1, i1;
+                wk.at(t0, k ? -1 : 1, j0, i0);
+                wk.at(t1, k ? -1 : 1, j1, i1);
+                uint32_t w0, s0, w1, s1, over;
+                vote_bin(vl, (float)j0, (float)i0, w0, s0, over);
+                vote_bin(vl, (float)j1, (float)i1, w1, s1, over);
+                atomicSub(&vl.words[w0], vl.one << s0);
+                atomicSub(&vl.words[w1], (two ? vl.one : 0u) << s1);
             }
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
