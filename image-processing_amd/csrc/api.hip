@@ -1128,13 +1128,22 @@ struct lc_pipe {
     std::vector<hipStream_t> st_lines_more;
     unsigned lines_turn = 0;
     // The streaming front kernel's unit height (fixed for the pipeline's largest batch: its change tracking is per unit)
-    // and, for pipelines whose ROI begins far down the frame, the row above which pixels are not classified at all:
-    // the final edge map is the hysteresis result INSIDE the ROI, and that depends on rows above the ROI only through
-    // weak pixels that connect the two.  The front kernel starts at row_split, BAND rows above the ROI's first row;
-    // launch_band_check proves per frame that no such connection can exist (a row of the band without leftover weak
-    // pixels), and the rare frame it cannot prove it for is classified again from row 0.  Not with intermediates
-    // (the pre-ROI edge map must then be complete).
+    // and, for pipelines with an ROI, which units it classifies at all.  The final edge map is the hysteresis result
+    // INSIDE the ROI, and that depends on pixels outside it only through weak pixels that connect the two.  The front
+    // kernel classifies the units (strip x row segment) that come within 15 pixels of the ROI; launch_ring_check proves per
+    // frame that nothing further out can matter (one of the 15 rings around the ROI without leftover weak pixels), and the
+    // rare frame it cannot prove it for is classified again in full.  Not with intermediates (the pre-ROI edge map
+    // must then be complete).  row_split: the first row of the lower region of the unit grid (rows above hold no
+    // needed unit).
     int front_rows = 0, row_split = 0, roi_first_row = 0;
+    bool roi_skip = false;
+    DevBuf<uint16_t> units_needed, units_unneeded;
+    int n_needed = 0, n_unneeded = 0, n_ring_words = 0;
+    DevBuf<uint32_t> ring_words;
+    DevBuf<uint64_t> ring_code;       // four bit planes: the ring number (1..15) of every pixel, 0 = in no ring
+    FrontSplit split(int mode, const int *only) const {
+        return FrontSplit{row_split, mode, only, units_needed.p, units_unneeded.p, n_needed, n_unneeded};
+    }
     bool fuse_vote = true;        // HoughLinesP's kernel also produces the full-vote accumulator (in LDS, before its own)
     // HoughLinesP with half a CU's LDS per frame, so that two frames -- of two batches, on two streams -- share a CU:
     // the kernel is one sequential wavefront per frame and leaves most of a CU idle.  For frame sizes whose working
@@ -1171,10 +1180,10 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     if (!points) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
                     w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p);
-    if (pp->row_split > 0) {
-        // frames that were classified in full: their plane rows above the split are cleared again, now that they
-        // have been read (a few workgroups that look at the flags and, nearly always, leave)
-        const FrontSplit clear{pp->row_split, 2, w.redo.p};
+    if (pp->roi_skip) {
+        // frames that were classified in full: the plane rows of the units no frame needs are cleared again, now that
+        // they have been read (a few workgroups that look at the flags and, nearly always, leave)
+        const FrontSplit clear = pp->split(2, w.redo.p);
         launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
                      nullptr, nullptr, es, nullptr, nullptr, nullptr, w.rowflags.p, pp->fused_dec3(), pp->front_rows, &clear);
     }
@@ -1255,20 +1264,20 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
         s.input = w.bgr.p;
         s.input_bytes = (size_t)n * 3 * w.npix;
     }
-    const FrontSplit skip{pp->row_split, 1, nullptr}, again{pp->row_split, 0, w.redo.p};
+    const FrontSplit skip = pp->split(1, nullptr), again = pp->split(0, w.redo.p);
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
                  pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize, pp->front_rows,
-                 pp->row_split > 0 ? &skip : nullptr);
+                 pp->roi_skip ? &skip : nullptr);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
     hipStream_t ps = pp->st_post;
     if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, s.ev[EV_FRONT], 0));
     launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status);
-    if (pp->row_split > 0) {
-        // frames for which the lower rows alone do not settle the ROI's edges: all rows again, and their hysteresis
+    if (pp->roi_skip) {
+        // frames for which the units near the ROI alone do not settle its edges: all units again, and their hysteresis
         // (both launches leave at once for the other frames, which is nearly always all of them)
-        launch_band_check(w.g, n, w.planeS.p, w.planeW.p, pp->row_split, pp->roi_first_row, w.redo.p, w.r_status, ps);
+        launch_ring_check(w.g, n, w.planeS.p, w.planeW.p, pp->ring_words.p, pp->n_ring_words, pp->ring_code.p, w.redo.p, w.r_status, ps);
         launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                      w.wake.p, nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p,
                      fused_resize, pp->front_rows, &again);
@@ -1370,9 +1379,10 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     }
 
     // ROI and car mask fold into one bit plane: keep = (roi == 255) && (car != 0)
+    std::vector<uint64_t> bits;
     if (p.roi_mask || p.car_mask) {
         const Geo g = pp->g;
-        std::vector<uint64_t> bits(g.plane_words(), 0);
+        bits.assign(g.plane_words(), 0);
         int roi_first = -1;
         for (int y = 0; y < g.H; y++)
             for (int x = 0; x < g.W; x++) {
@@ -1400,12 +1410,87 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     }
 
     {
-        constexpr int BAND = 16;            // rows between row_split and the ROI in which a clean row is looked for
         static const char *ns = getenv("LANECV_NO_ROW_SKIP");
-        if (pp->has_roi && !p.keep_intermediates && front_stream_supported(pp->g) && !getenv("LANECV_FRONT_TILED") && !ns &&
-            pp->roi_first_row - BAND >= 64)
-            pp->row_split = pp->roi_first_row - BAND;
-        pp->front_rows = front_stream_rows_per_unit(pp->g, p.max_batch, p.height - pp->row_split);
+        const Geo g = pp->g;
+        if (pp->has_roi && !p.keep_intermediates && front_stream_supported(g) && !getenv("LANECV_FRONT_TILED") && !ns) {
+            // rings 1..15 around the ROI by fifteen 3x3 dilations of its bit plane
+            constexpr int NRING = 15;
+            const int TX = g.TX, H = g.H;
+            const uint64_t last_mask = (g.W & 63) ? ((1ull << (g.W & 63)) - 1) : ~0ull;
+            auto dilate = [&](const std::vector<uint64_t> &in) {
+                std::vector<uint64_t> hz(in.size()), out(in.size());
+                for (int y = 0; y < H; y++)
+                    for (int tx = 0; tx < TX; tx++) {
+                        const uint64_t c = in[(size_t)y * TX + tx];
+                        const uint64_t l = tx > 0 ? in[(size_t)y * TX + tx - 1] >> 63 : 0, r = tx + 1 < TX ? in[(size_t)y * TX + tx + 1] << 63 : 0;
+                        uint64_t v = c | (c << 1) | (c >> 1) | l | r;
+                        if (tx == TX - 1) v &= last_mask;
+                        hz[(size_t)y * TX + tx] = v;
+                    }
+                for (int y = 0; y < H; y++)
+                    for (int tx = 0; tx < TX; tx++) {
+                        uint64_t v = hz[(size_t)y * TX + tx];
+                        if (y > 0) v |= hz[(size_t)(y - 1) * TX + tx];
+                        if (y + 1 < H) v |= hz[(size_t)(y + 1) * TX + tx];
+                        out[(size_t)y * TX + tx] = v;
+                    }
+                return out;
+            };
+            std::vector<uint64_t> cur = bits, code(4 * bits.size(), 0);
+            for (int k = 1; k <= NRING; k++) {
+                std::vector<uint64_t> nxt = dilate(cur);
+                for (size_t i = 0; i < bits.size(); i++) {
+                    const uint64_t ring = nxt[i] & ~cur[i];
+                    for (int b = 0; b < 4; b++)
+                        if (k & (1 << b)) code[b * bits.size() + i] |= ring;
+                }
+                cur.swap(nxt);
+            }
+            int first = -1;
+            for (int y = 0; y < H && first < 0; y++)
+                for (int tx = 0; tx < TX; tx++)
+                    if (cur[(size_t)y * TX + tx]) { first = y; break; }
+            if (first >= 0) {
+                pp->row_split = first >= 64 ? first : 0;
+                pp->front_rows = front_stream_rows_per_unit(g, p.max_batch, H - pp->row_split);
+                const FrontGrid fg = front_stream_grid(g, pp->front_rows, pp->row_split);
+                std::vector<uint16_t> needed, unneeded;
+                for (int sg = 0; sg < fg.nseg_top + fg.nseg_low; sg++)
+                    for (int st = 0; st < fg.nstrips; st++) {
+                        bool need = false;
+                        if (sg >= fg.nseg_top) {
+                            const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
+                            const int x0 = st * fg.strip_cols, x1 = std::min(x0 + fg.strip_cols, g.W);
+                            for (int y = y0; y < y1 && !need; y++)
+                                for (int tx = x0 >> 6; tx <= (x1 - 1) >> 6 && tx < TX && !need; tx++) {
+                                    uint64_t v = cur[(size_t)y * TX + tx];
+                                    const int lo = std::max(x0 - tx * 64, 0), hi = std::min(x1 - tx * 64, 64);   // bits [lo, hi) of the word
+                                    if (lo > 0) v &= ~((1ull << lo) - 1);
+                                    if (hi < 64) v &= (1ull << hi) - 1;
+                                    need = v != 0;
+                                }
+                        }
+                        (need ? needed : unneeded).push_back((uint16_t)(sg | (st << 8)));
+                    }
+                std::vector<uint32_t> rw;
+                for (size_t i = 0; i < bits.size(); i++)
+                    if (code[i] | code[bits.size() + i] | code[2 * bits.size() + i] | code[3 * bits.size() + i]) rw.push_back((uint32_t)i);
+                if (!needed.empty() && !unneeded.empty() && fg.nseg_top + fg.nseg_low < 256 && fg.nstrips < 256) {
+                    if ((rc = pp->units_needed.alloc(needed.size())) || (rc = pp->units_unneeded.alloc(unneeded.size())) ||
+                        (rc = pp->ring_words.alloc(rw.size())) || (rc = pp->ring_code.alloc(code.size()))) { delete pp; return rc; }
+                    hipError_t e = hipMemcpy(pp->units_needed.p, needed.data(), needed.size() * 2, hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMemcpy(pp->units_unneeded.p, unneeded.data(), unneeded.size() * 2, hipMemcpyHostToDevice);
+                    if (e == hipSuccess && !rw.empty()) e = hipMemcpy(pp->ring_words.p, rw.data(), rw.size() * 4, hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMemcpy(pp->ring_code.p, code.data(), code.size() * 8, hipMemcpyHostToDevice);
+                    if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "unit list upload failed: %s", hipGetErrorString(e)); }
+                    pp->n_needed = (int)needed.size(); pp->n_unneeded = (int)unneeded.size(); pp->n_ring_words = (int)rw.size();
+                    pp->roi_skip = true;
+                } else {
+                    pp->row_split = 0;
+                }
+            }
+        }
+        if (!pp->roi_skip) pp->front_rows = front_stream_rows_per_unit(g, p.max_batch, g.H);
     }
     {
         // All streams have the same priority.  With the post and HoughLinesP streams at high priority their few
@@ -1732,7 +1817,7 @@ int lc_pipe_row_skip(lc_pipe *pipe, int slot, int *first_row, int *frames_redone
     if (first_row) *first_row = pipe->row_split;
     if (frames_redone) {
         *frames_redone = 0;
-        if (pipe->row_split > 0 && s->nframes > 0) {
+        if (pipe->roi_skip && s->nframes > 0) {
             std::vector<int> redo(s->nframes);
             HIP_TRY(hipMemcpy(redo.data(), s->w.redo.p, sizeof(int) * s->nframes, hipMemcpyDeviceToHost));
             for (int v : redo) *frames_redone += v != 0;

@@ -78,16 +78,22 @@ void launch_gray(const uint8_t *bgr, int W, int H, int nframes, int code, uint8_
 bool front_stream_supported(Geo g);
 int front_stream_strips(Geo g);     // 248-column strips per frame row
 int front_stream_rows_per_unit(Geo g, int max_batch, int rows_classified);   // rows_classified: 0 = all of them
-// Rows the final edge map cannot depend on need not be classified.  With an ROI whose first row is far down the frame, a
-// pipeline splits the frame at row_split: a launch in mode 1 classifies rows >= row_split only; launch_band_check then
-// decides per frame whether that was enough; a launch in mode 0 with only_frames redoes the frames for which it was not,
-// from row 0; and once their planes have been consumed a launch in mode 2 (with the same flags) clears the plane rows
-// above row_split that the full pass stored, so that the next batch finds them empty again.
+// Pixels the final edge map cannot depend on need not be classified.  With an ROI a pipeline classifies only the units
+// (strip x row segment) that come within RING pixels of it: a launch in mode 1 does those (`needed`, or without a list all
+// units from row_split down); launch_ring_check then decides per frame whether that was enough; a launch in mode 0 with
+// only_frames redoes the frames for which it was not, all units; and once their planes have been consumed a launch in mode
+// 2 (with the same flags) clears the plane rows of the other units (`unneeded`) that the full pass stored, so that the
+// next batch finds them empty again.
 struct FrontSplit {
-    int row_split;              // > 0: first row of the lower region
-    int mode;                   // 0: all rows; 1: rows >= row_split only; 2: clear the plane rows above row_split
+    int row_split;              // > 0: rows above it form a region of units of their own (never needed)
+    int mode;                   // 0: all units; 1: the needed units only; 2: clear the plane rows of the unneeded units
     const int *only_frames;     // device flags, one per frame, or null: frames whose flag is 0 are left alone
+    const uint16_t *needed, *unneeded;    // device lists of units (segment | strip << 8), or null
+    int nneeded, nunneeded;
 };
+// the unit grid of a frame for a unit height and a split row (what launch_front_stream uses; for building unit lists)
+struct FrontGrid { int nseg_top, rows_top, nseg_low, rows_low, nstrips, strip_cols; };
+FrontGrid front_stream_grid(Geo g, int rows_per_unit, int row_split);
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                          int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags = nullptr,
@@ -119,12 +125,16 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st, int *status = nullptr, const int *only_frames = nullptr);
 // only_frames (may be null): device flags, one per frame; frames whose flag is 0 are left alone
-// After hysteresis over the rows >= row_split only: redo[f] = 1 if none of the rows [row_split, roi_first_row) of frame f
-// is free of weak pixels that stayed weak.  (A connection from an ROI pixel to a strong pixel above row_split would have
-// to pass through such a pixel in every one of those rows; one clean row proves there is none.)  status (may be null):
-// word 3 is set if any frame was flagged.
-void launch_band_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, int row_split, int roi_first_row,
-                       int *redo, int *status, hipStream_t st);
+// After hysteresis over the needed units only: does anything outside them matter to frame f?  Ring k = the pixels at
+// Chebyshev distance k from the ROI (k = 1..15; the needed units cover them all).  A chain of candidate pixels from an
+// ROI pixel to a strong pixel further out passes through every ring (the distance changes by at most one per step), and
+// if the ROI pixel is not an edge already, every pixel of the chain inside the rings is a weak pixel that stayed weak.
+// redo[f] = 1 iff such pixels connect ring 1 to ring 15 (8-neighbours, flooded from all of ring 1's), or there are too
+// many of them to tell.
+// ring_words: indices of the plane words that hold ring pixels; code[b]: bit plane b of the ring number (0 = no ring).
+// status (may be null): word 3 is set if any frame was flagged.
+void launch_ring_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, const uint32_t *ring_words,
+                       int nring_words, const uint64_t *code, int *redo, int *status, hipStream_t st);
 // roi_bits: one plane shared by all frames, or nullptr
 // prevbits (may be null): the masked bits of the previous call on the same masked_out / rowplane buffers, all
 // zero before the first (like those buffers); with it, and without edges_out, only what changed is written

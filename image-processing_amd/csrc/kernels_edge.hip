@@ -429,26 +429,76 @@ __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__re
 }
 
 // ---------------------------------------------------------------------------
-// Was it enough to classify the rows from row_split down?  One wavefront per frame looks at the rows between
-// row_split and the first row of the ROI: a row without a weak pixel that stayed weak separates everything below it
-// from whatever lies above row_split (see launch_band_check in common.h).
+// Was it enough to classify the units near the ROI?  One wavefront per frame (see launch_ring_check in common.h).
+// A pixel outside the classified units can only matter through a chain of weak pixels that stayed weak, leading from
+// the ROI outwards through every ring.  The wavefront lists the leftover weak pixels of the rings (there are few),
+// takes those of ring 1 as reached -- as if every one of them touched such a pixel of the ROI -- and floods from
+// them through 8-neighbours in the list; only if the flood arrives in ring 15 (or the list overflows) is the frame
+// classified again in full.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_band_check(Geo g, const uint64_t *__restrict__ planeS, const uint64_t *__restrict__ planeW,
-                                                   int row_split, int roi_first_row, int *__restrict__ redo,
+constexpr int RING_LIST = 512;
+__global__ __launch_bounds__(64) void k_ring_check(Geo g, const uint64_t *__restrict__ planeS, const uint64_t *__restrict__ planeW,
+                                                   const uint32_t *__restrict__ ring_words, int nring_words,
+                                                   const uint64_t *__restrict__ code, int *__restrict__ redo,
                                                    int *__restrict__ status) {
+    __shared__ uint32_t px[RING_LIST];        // x | y << 13 | ring << 26 | reached << 31
+    __shared__ int count;
     const int f = blockIdx.x, lane = threadIdx.x;
-    bool clean_row = false;
-    for (int y = row_split; y < roi_first_row && !clean_row; y++) {
+    const size_t words = g.plane_words();
+    if (lane == 0) count = 0;
+    __syncthreads();
+    bool overflow = false;
+    for (int i0 = 0; i0 < nring_words; i0 += 64) {
+        const int i = i0 + lane;
         uint64_t left = 0;
-        for (int tx = lane; tx < g.TX; tx += 64) {
-            const size_t i = ((size_t)f * g.H + y) * g.TX + tx;
-            left |= planeW[i] & ~planeS[i];
+        uint32_t w = 0;
+        if (i < nring_words) {
+            w = ring_words[i];
+            left = planeW[(size_t)f * words + w] & ~planeS[(size_t)f * words + w];
+            if (left) left &= code[w] | code[words + w] | code[2 * words + w] | code[3 * words + w];   // ring pixels only
         }
-        clean_row = __ballot(left != 0) == 0;
+        if (__ballot(left != 0) == 0) continue;
+        if (left) {
+            const uint64_t c0 = code[w], c1 = code[words + w], c2 = code[2 * words + w], c3 = code[3 * words + w];
+            const int n = __popcll(left);
+            const int at = atomicAdd(&count, n);
+            const uint32_t y = w / g.TX, xb = (w % g.TX) * 64;
+            int k = 0;
+            for (uint64_t m = left; m; m &= m - 1, k++) {
+                const int b = __builtin_ctzll(m);
+                const uint32_t ring = (uint32_t)((c0 >> b) & 1) | (uint32_t)((c1 >> b) & 1) << 1 | (uint32_t)((c2 >> b) & 1) << 2 |
+                                      (uint32_t)((c3 >> b) & 1) << 3;
+                if (at + k < RING_LIST) px[at + k] = (xb + b) | (y << 13) | (ring << 26) | ((ring == 1 ? 1u : 0u) << 31);
+            }
+        }
     }
+    __syncthreads();
+    const int n = count;
+    overflow = n > RING_LIST;
+    bool arrived = false;
+    if (!overflow) {
+        for (;;) {          // at most n rounds: every round but the last reaches a new pixel
+            bool changed = false;
+            for (int i = lane; i < n; i += 64) {
+                const uint32_t p = px[i];
+                if (p >> 31) continue;
+                const int x = p & 0x1FFF, y = (p >> 13) & 0x1FFF;
+                bool hit = false;
+                for (int j = 0; j < n && !hit; j++) {
+                    const uint32_t q = px[j];
+                    hit = (q >> 31) && abs((int)(q & 0x1FFF) - x) <= 1 && abs((int)((q >> 13) & 0x1FFF) - y) <= 1;
+                }
+                if (hit) { px[i] = p | 0x80000000u; changed = true; }
+            }
+            __syncthreads();
+            if (__ballot(changed) == 0) break;
+        }
+        for (int i = lane; i < n; i += 64) arrived |= (px[i] >> 31) && ((px[i] >> 26) & 15) == 15;
+    }
+    const bool bad = overflow || __ballot(arrived) != 0;
     if (lane == 0) {
-        redo[f] = clean_row ? 0 : 1;
-        if (!clean_row && status) status[3] = 1;        // (a plain store: the words may live in host memory)
+        redo[f] = bad ? 1 : 0;
+        if (bad && status) status[3] = 1;        // (a plain store: the words may live in host memory)
     }
 }
 
@@ -645,9 +695,9 @@ void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *pla
     hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds, status, only_frames);
 }
 
-void launch_band_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, int row_split, int roi_first_row,
-                       int *redo, int *status, hipStream_t st) {
-    hipLaunchKernelGGL(k_band_check, dim3(nframes), dim3(64), 0, st, g, planeS, planeW, row_split, roi_first_row, redo, status);
+void launch_ring_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, const uint32_t *ring_words,
+                       int nring_words, const uint64_t *code, int *redo, int *status, hipStream_t st) {
+    hipLaunchKernelGGL(k_ring_check, dim3(nframes), dim3(64), 0, st, g, planeS, planeW, ring_words, nring_words, code, redo, status);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,

@@ -153,6 +153,10 @@ struct FrontArgs {
     // look at a flag would cost more than the check is worth); group j does the flagged frames j, j + GROUPS, ...
     const int *only_frames;
     int nframes;
+    // if set: the launch covers, per frame, only the nlist units listed (unit = segment | strip << 8) -- the units an
+    // ROI needs (FrontSplit) or, for the clearing launch, the others
+    const uint16_t *unit_list;
+    int nlist;
     int wg_chunk;            // logical workgroups per XCD (see the kernel)
     const int *gate_tab;     // GATE only: the gate's tables in device memory (gate_tables_host)
     GateDev gate;
@@ -507,8 +511,11 @@ __device__ __forceinline__ void front_stream_body(const FrontArgs &a) {
     const int wgl = (int)(blockIdx.x & 7u) * a.wg_chunk + (int)(blockIdx.x >> 3);
     const int u = __builtin_amdgcn_readfirstlane(wgl * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // wave-uniform
     if (u >= a.nunits) return;
-    const int s = u % a.nstrips;
-    const int sg = a.seg_first + (u / a.nstrips) % a.nseg;
+    const int per_frame = a.unit_list ? a.nlist : a.nstrips * a.nseg;
+    const int ui = u % per_frame;
+    int s, sg;
+    if (a.unit_list) { const int e = a.unit_list[ui]; sg = e & 255; s = e >> 8; }
+    else { s = ui % a.nstrips; sg = a.seg_first + ui / a.nstrips; }
     const int H = a.g.H;
     constexpr int DB = BLUR ? 2 : 0;
     int y0, y1;
@@ -530,7 +537,7 @@ __device__ __forceinline__ void front_stream_body(const FrontArgs &a) {
     };
     // every frame: the workgroup's one frame.  Flagged frames only: this wavefront's share of the flags in one
     // load, then frame after frame (one call site either way: the unit's code is inlined there)
-    const int j = u / (a.nstrips * a.nseg);
+    const int j = u / per_frame;
     for (int base = j; base < a.nframes; base += REDO_GROUPS * 64) {
         uint64_t todo = 1;
         if (a.only_frames) {
@@ -557,8 +564,10 @@ __global__ __launch_bounds__(256) void k_front_clear(FrontArgs a) {
     const int wgl = (int)(blockIdx.x & 7u) * a.wg_chunk + (int)(blockIdx.x >> 3);
     const int u = __builtin_amdgcn_readfirstlane(wgl * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
     if (u >= a.nunits) return;
-    const int s = u % a.nstrips, sg = (u / a.nstrips) % a.nseg, j = u / (a.nstrips * a.nseg);
-    const int y0 = sg * a.rows_top, y1 = min(y0 + a.rows_top, a.row_split);
+    const int e = a.unit_list[u % a.nlist], sg = e & 255, s = e >> 8, j = u / a.nlist;
+    int y0, y1;
+    if (sg < a.nseg_top) { y0 = sg * a.rows_top; y1 = min(y0 + a.rows_top, a.row_split); }
+    else { y0 = a.row_split + (sg - a.nseg_top) * a.rows_per_unit; y1 = min(y0 + a.rows_per_unit, a.g.H); }
     for (int base = j; base < a.nframes; base += REDO_GROUPS * 64) {
         const int fl = base + REDO_GROUPS * (int)(threadIdx.x & 63);
         uint64_t todo = __ballot(fl < a.nframes && a.only_frames[fl] != 0);
@@ -587,6 +596,25 @@ int front_stream_rows_per_unit(Geo g, int max_batch, int rows_classified) {
     return rows > g.H ? g.H : rows;
 }
 
+// the unit grid of a frame: rows [0, row_split) and [row_split, H) each in units of about rows_per_unit rows
+FrontGrid front_stream_grid(Geo g, int rows_per_unit, int row_split) {
+    FrontGrid fg{};
+    if (rows_per_unit > g.H) rows_per_unit = g.H;
+    if (rows_per_unit < 1) rows_per_unit = 1;
+    const int rows_low = g.H - row_split;
+    fg.nseg_low = (rows_low + rows_per_unit - 1) / rows_per_unit;
+    fg.rows_low = rows_per_unit;
+    if (row_split > 0) {
+        fg.nseg_top = (row_split + rows_per_unit - 1) / rows_per_unit;
+        fg.rows_top = (row_split + fg.nseg_top - 1) / fg.nseg_top;
+        fg.rows_low = (rows_low + fg.nseg_low - 1) / fg.nseg_low;
+        fg.nseg_low = (rows_low + fg.rows_low - 1) / fg.rows_low;
+    }
+    fg.nstrips = front_stream_strips(g);
+    fg.strip_cols = STRIP;
+    return fg;
+}
+
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                          int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags, bool dec3,
@@ -608,21 +636,21 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.rows_per_unit = rows_per_unit;
     a.row_split = split ? split->row_split : 0;
     a.only_frames = split ? split->only_frames : nullptr;
-    a.nseg_top = a.rows_top = a.seg_first = a.clear_top = 0;
-    const int rows_low = g.H - a.row_split;
-    int nseg_low = (rows_low + rows_per_unit - 1) / rows_per_unit;
-    if (a.row_split > 0) {                           // both regions in units of about the same height
-        a.nseg_top = (a.row_split + rows_per_unit - 1) / rows_per_unit;
-        a.rows_top = (a.row_split + a.nseg_top - 1) / a.nseg_top;
-        a.rows_per_unit = (rows_low + nseg_low - 1) / nseg_low;
-        nseg_low = (rows_low + a.rows_per_unit - 1) / a.rows_per_unit;
+    a.unit_list = nullptr;
+    a.nlist = 0;
+    a.seg_first = a.clear_top = 0;
+    const FrontGrid fg = front_stream_grid(g, rows_per_unit, a.row_split);
+    a.nseg_top = fg.nseg_top; a.rows_top = fg.rows_top; a.rows_per_unit = fg.rows_low;
+    a.nseg = fg.nseg_top + fg.nseg_low;
+    if (split && split->mode == 1) {
+        if (split->needed) { a.unit_list = split->needed; a.nlist = split->nneeded; }
+        else { a.seg_first = fg.nseg_top; a.nseg = fg.nseg_low; }
     }
-    a.nseg = a.nseg_top + nseg_low;
-    if (split && split->mode == 1) { a.seg_first = a.nseg_top; a.nseg = nseg_low; }
-    if (split && split->mode == 2) { a.nseg = a.nseg_top; a.clear_top = 1; }
-    if (a.nseg == 0) return;
+    if (split && split->mode == 2) { a.unit_list = split->unneeded; a.nlist = split->nunneeded; a.clear_top = 1; }
+    const int per_frame = a.unit_list ? a.nlist : a.nseg * a.nstrips;
+    if (per_frame == 0 || (a.clear_top && !a.unit_list)) return;
     a.nframes = nframes;
-    a.nunits = (a.only_frames ? std::min(REDO_GROUPS, nframes) : nframes) * a.nseg * a.nstrips;
+    a.nunits = (a.only_frames ? std::min(REDO_GROUPS, nframes) : nframes) * per_frame;
     // no LDS and no barrier: one wavefront per workgroup, so that a unit can start wherever a single wave slot
     // is free (LANECV_FRONT_WAVES overrides: waves per workgroup, 1..4)
     static const char *wv_env = getenv("LANECV_FRONT_WAVES");

@@ -350,7 +350,7 @@ def test_rows_above_the_roi_are_skipped_exactly(oracle):
 
     road = [synth.synth_road(w, h, seed=41, t=t) for t in range(4)]
     first, redone = pipe.row_skip(0)
-    assert first == h // 2 - 16 and redone == 0
+    assert first == h // 2 - 15 and redone == 0
     batches = [
         np.stack(road),
         np.stack([road[0], faint_edge(w // 2 + 40, 100), road[1], faint_edge(w // 2 + 90, 30, flip=True), road[2]]),
