@@ -1137,6 +1137,7 @@ struct lc_pipe {
     // needed unit).
     int front_rows = 0, row_split = 0, roi_first_row = 0;
     bool roi_skip = false;
+    long long classified_pixels = 0;  // pixels per frame of the units the front kernel classifies (all of them without an ROI)
     DevBuf<uint16_t> units_needed, units_unneeded;
     int n_needed = 0, n_unneeded = 0, n_ring_words = 0;
     DevBuf<uint32_t> ring_words;
@@ -1455,6 +1456,7 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
                 pp->front_rows = front_stream_rows_per_unit(g, p.max_batch, H - pp->row_split);
                 const FrontGrid fg = front_stream_grid(g, pp->front_rows, pp->row_split);
                 std::vector<uint16_t> needed, unneeded;
+                long long npix = 0;
                 for (int sg = 0; sg < fg.nseg_top + fg.nseg_low; sg++)
                     for (int st = 0; st < fg.nstrips; st++) {
                         bool need = false;
@@ -1471,6 +1473,11 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
                                 }
                         }
                         (need ? needed : unneeded).push_back((uint16_t)(sg | (st << 8)));
+                        if (need) {
+                            const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
+                            const int x0 = st * fg.strip_cols, x1 = std::min(x0 + fg.strip_cols, g.W);
+                            npix += (long long)(y1 - y0) * (x1 - x0);
+                        }
                     }
                 std::vector<uint32_t> rw;
                 for (size_t i = 0; i < bits.size(); i++)
@@ -1485,12 +1492,16 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
                     if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "unit list upload failed: %s", hipGetErrorString(e)); }
                     pp->n_needed = (int)needed.size(); pp->n_unneeded = (int)unneeded.size(); pp->n_ring_words = (int)rw.size();
                     pp->roi_skip = true;
+                    pp->classified_pixels = npix;
                 } else {
                     pp->row_split = 0;
                 }
             }
         }
-        if (!pp->roi_skip) pp->front_rows = front_stream_rows_per_unit(g, p.max_batch, g.H);
+        if (!pp->roi_skip) {
+            pp->front_rows = front_stream_rows_per_unit(g, p.max_batch, g.H);
+            pp->classified_pixels = (long long)g.W * g.H;
+        }
     }
     {
         // All streams have the same priority.  With the post and HoughLinesP streams at high priority their few
@@ -1809,12 +1820,13 @@ int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_to
     return LC_OK;
 }
 
-int lc_pipe_row_skip(lc_pipe *pipe, int slot, int *first_row, int *frames_redone) {
+int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_classified, int *frames_redone) {
     Slot *s;
     int rc;
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
     if (first_row) *first_row = pipe->row_split;
+    if (pixels_classified) *pixels_classified = pipe->classified_pixels;
     if (frames_redone) {
         *frames_redone = 0;
         if (pipe->roi_skip && s->nframes > 0) {

@@ -263,10 +263,16 @@ class LanePipeline:
         return a.value, b.value
 
     def row_skip(self, slot=0):
-        """(first row the edge kernel classifies, frames of the slot's last batch that needed all rows after all)."""
-        a, b = C.c_int(), C.c_int()
-        _abi.check(_abi.lib().lc_pipe_row_skip(self._h, slot, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        """(first row of which the edge kernel classifies anything, frames of the slot's last batch that needed the whole
+        frame after all)."""
+        first, _, redone = self.roi_skip(slot)
+        return first, redone
+
+    def roi_skip(self, slot=0):
+        """(first row classified, pixels per frame the edge kernel classifies, frames of the slot's last batch redone in full)."""
+        a, b, c = C.c_int(), C.c_longlong(), C.c_int()
+        _abi.check(_abi.lib().lc_pipe_roi_skip(self._h, slot, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def shared_queues(self):
         """Streams of the pipeline that found no hardware queue of their own (0 = full overlap)."""

@@ -257,11 +257,12 @@ int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr);
 /* Hysteresis diagnostics of the slot's last batch: rounds until the fixed point (the first
  * included), maximum over the frames and total. */
 int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_total);
-/* Diagnostics with no counterpart in the reference.  A pipeline whose ROI begins far down the frame does not classify
- * the rows above it (the result inside the ROI is proven independent of them per frame, and a frame for which it
- * cannot be proven is classified again in full): *first_row = the first row classified (0: all rows),
- * *frames_redone = frames of the slot's last batch that needed the full pass.  Either pointer may be NULL. */
-int lc_pipe_row_skip(lc_pipe *pipe, int slot, int *first_row, int *frames_redone);
+/* Diagnostics with no counterpart in the reference.  A pipeline with an ROI classifies only the parts of a frame within 15
+ * pixels of it (the result inside the ROI is proven independent of the rest per frame, and a frame for which it cannot be
+ * proven is classified again in full): *first_row = the first row of which anything is classified (0: from the top),
+ * *pixels_classified = pixels per frame the edge kernel classifies (width x height without an ROI), *frames_redone = frames
+ * of the slot's last batch that needed the full pass.  Any pointer may be NULL. */
+int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_classified, int *frames_redone);
 /* Diagnostics with no counterpart in the reference: how many of the pipeline's streams found no hardware queue of
  * their own when it was created (HIP folds a process's streams onto GPU_MAX_HW_QUEUES queues; the pipeline probes
  * which ones share).  0 = every stage overlaps as designed; otherwise stages that were meant to run side by side
