@@ -1079,6 +1079,8 @@ struct Slot {
     const uint8_t *input = nullptr;   // device pointer of the frames of the batch in flight
     size_t input_bytes = 0;
     bool busy = false, timed = false;
+    int level = 0;                // ROI-scheme level of the batch in flight (or last); the pipeline's nlevels = classified in full
+    int planes_level = 0;         // loosest level a batch of this slot ran at since its planes were last cleared down
     // pinned host mirror of the slot's result block
     int32_t *h_res = nullptr;
     bool zero_copy = false;       // the kernels write the result block straight into h_res (mapped pinned memory)
@@ -1136,14 +1138,28 @@ struct lc_pipe {
     // must then be complete).  row_split: the first row of the lower region of the unit grid (rows above hold no
     // needed unit).
     int front_rows = 0, row_split = 0, roi_first_row = 0;
-    bool roi_skip = false;
-    long long classified_pixels = 0;  // pixels per frame of the units the front kernel classifies (all of them without an ROI)
-    DevBuf<uint16_t> units_needed, units_unneeded;
-    int n_needed = 0, n_unneeded = 0, n_ring_words = 0;
-    DevBuf<uint32_t> ring_words;
-    DevBuf<uint64_t> ring_code;       // four bit planes: the ring number (1..15) of every pixel, 0 = in no ring
-    FrontSplit split(int mode, const int *only) const {
-        return FrontSplit{row_split, mode, only, units_needed.p, units_unneeded.p, n_needed, n_unneeded};
+    // Levels of the scheme, tightest first: [0] the units within 15 pixels of the ROI, rings around the ROI; [1] all units
+    // from row_split down, "rings" = the rows between row_split and the ROI's first row (the same proof around the band of
+    // rows the ROI spans: for recipes whose weak pixels connect everything near the ROI, as the F1 tracker's low Canny
+    // thresholds do, but not the sky above it).  `level` is what the next batch uses; nlevels = classify in full.  A batch
+    // in which more than a sixteenth of the frames needed the full pass after all moves the pipeline one level out for
+    // the next 256 batches, after which it tries one level in again.  A slot that goes back to a tighter level has the
+    // plane rows of the units that level does not need cleared first (for every frame: `ones`).
+    struct SkipLevel {
+        DevBuf<uint16_t> needed, unneeded;      // units: segment | strip << 8
+        int n_needed = 0, n_unneeded = 0, n_ring_words = 0;
+        DevBuf<uint32_t> ring_words;            // plane words that hold ring pixels
+        DevBuf<uint64_t> ring_code;             // four bit planes: the ring number (1..15) of every pixel, 0 = in no ring
+        long long pixels = 0;                   // pixels per frame of the needed units
+    };
+    SkipLevel levels[2];
+    int nlevels = 0, level = 0, level_hold = 0;
+    DevBuf<int> ones;
+    long long frame_pixels = 0;
+    FrontSplit split(int lvl, int mode, const int *only) const {
+        if (lvl >= nlevels) return FrontSplit{row_split, 0, only, nullptr, nullptr, 0, 0};
+        const SkipLevel &L = levels[lvl];
+        return FrontSplit{row_split, mode, only, L.needed.p, L.unneeded.p, L.n_needed, L.n_unneeded};
     }
     bool fuse_vote = true;        // HoughLinesP's kernel also produces the full-vote accumulator (in LDS, before its own)
     // HoughLinesP with half a CU's LDS per frame, so that two frames -- of two batches, on two streams -- share a CU:
@@ -1181,10 +1197,10 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     if (!points) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
                     w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p);
-    if (pp->roi_skip) {
+    if (s.level < pp->nlevels) {
         // frames that were classified in full: the plane rows of the units no frame needs are cleared again, now that
         // they have been read (a few workgroups that look at the flags and, nearly always, leave)
-        const FrontSplit clear = pp->split(2, w.redo.p);
+        const FrontSplit clear = pp->split(s.level, 2, w.redo.p);
         launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
                      nullptr, nullptr, es, nullptr, nullptr, nullptr, w.rowflags.p, pp->fused_dec3(), pp->front_rows, &clear);
     }
@@ -1265,20 +1281,37 @@ int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
         s.input = w.bgr.p;
         s.input_bytes = (size_t)n * 3 * w.npix;
     }
-    const FrontSplit skip = pp->split(1, nullptr), again = pp->split(0, w.redo.p);
+    if (pp->level > 0 && pp->nlevels > 0) {
+        if (pp->level_hold > 0) pp->level_hold--;
+        else { pp->level--; pp->level_hold = 0; }     // try one level in again
+    }
+    s.level = pp->nlevels > 0 ? pp->level : 0;
+    const bool skipping = s.level < pp->nlevels;
+    const FrontSplit skip = pp->split(s.level, 1, nullptr), again = pp->split(pp->nlevels, 0, w.redo.p);
+    if (pp->nlevels > 0) {
+        if (s.level < s.planes_level) {      // back at a tighter level: the plane rows of the units it does not need go first
+            const FrontSplit clear_all = pp->split(s.level, 2, pp->ones.p);
+            launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
+                         w.wake.p, nullptr, nullptr, es, nullptr, nullptr, nullptr, w.rowflags.p, pp->fused_dec3(), pp->front_rows,
+                         &clear_all);
+        }
+        s.planes_level = s.level;
+    }
     launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
                  pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize, pp->front_rows,
-                 pp->roi_skip ? &skip : nullptr);
+                 pp->nlevels > 0 ? &skip : nullptr);
     HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
     if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
     hipStream_t ps = pp->st_post;
     if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, s.ev[EV_FRONT], 0));
     launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status);
-    if (pp->roi_skip) {
+    if (skipping) {
         // frames for which the units near the ROI alone do not settle its edges: all units again, and their hysteresis
         // (both launches leave at once for the other frames, which is nearly always all of them)
-        launch_ring_check(w.g, n, w.planeS.p, w.planeW.p, pp->ring_words.p, pp->n_ring_words, pp->ring_code.p, w.redo.p, w.r_status, ps);
+        const lc_pipe::SkipLevel &L = pp->levels[s.level];
+        launch_ring_check(w.g, n, w.planeS.p, w.planeW.p, L.ring_words.p, L.n_ring_words, L.ring_code.p, w.redo.p, w.r_status, ps,
+                          w.r_rounds);
         launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                      w.wake.p, nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p,
                      fused_resize, pp->front_rows, &again);
@@ -1455,54 +1488,82 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
                 pp->row_split = first >= 64 ? first : 0;
                 pp->front_rows = front_stream_rows_per_unit(g, p.max_batch, H - pp->row_split);
                 const FrontGrid fg = front_stream_grid(g, pp->front_rows, pp->row_split);
-                std::vector<uint16_t> needed, unneeded;
-                long long npix = 0;
-                for (int sg = 0; sg < fg.nseg_top + fg.nseg_low; sg++)
-                    for (int st = 0; st < fg.nstrips; st++) {
-                        bool need = false;
-                        if (sg >= fg.nseg_top) {
-                            const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
-                            const int x0 = st * fg.strip_cols, x1 = std::min(x0 + fg.strip_cols, g.W);
-                            for (int y = y0; y < y1 && !need; y++)
-                                for (int tx = x0 >> 6; tx <= (x1 - 1) >> 6 && tx < TX && !need; tx++) {
-                                    uint64_t v = cur[(size_t)y * TX + tx];
-                                    const int lo = std::max(x0 - tx * 64, 0), hi = std::min(x1 - tx * 64, 64);   // bits [lo, hi) of the word
-                                    if (lo > 0) v &= ~((1ull << lo) - 1);
-                                    if (hi < 64) v &= (1ull << hi) - 1;
-                                    need = v != 0;
-                                }
+                // uploads one level: the units a region `reach` (bit plane) touches, and the ring code planes around it
+                auto add_level = [&](const std::vector<uint64_t> &reach, const std::vector<uint64_t> &rcode) -> int {
+                    std::vector<uint16_t> needed, unneeded;
+                    long long npix = 0;
+                    for (int sg = 0; sg < fg.nseg_top + fg.nseg_low; sg++)
+                        for (int st = 0; st < fg.nstrips; st++) {
+                            bool need = false;
+                            if (sg >= fg.nseg_top) {
+                                const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
+                                const int x0 = st * fg.strip_cols, x1 = std::min(x0 + fg.strip_cols, g.W);
+                                for (int y = y0; y < y1 && !need; y++)
+                                    for (int tx = x0 >> 6; tx <= (x1 - 1) >> 6 && tx < TX && !need; tx++) {
+                                        uint64_t v = reach[(size_t)y * TX + tx];
+                                        const int lo = std::max(x0 - tx * 64, 0), hi = std::min(x1 - tx * 64, 64);   // bits [lo, hi) of the word
+                                        if (lo > 0) v &= ~((1ull << lo) - 1);
+                                        if (hi < 64) v &= (1ull << hi) - 1;
+                                        need = v != 0;
+                                    }
+                                if (need) npix += (long long)(y1 - y0) * (x1 - x0);
+                            }
+                            (need ? needed : unneeded).push_back((uint16_t)(sg | (st << 8)));
                         }
-                        (need ? needed : unneeded).push_back((uint16_t)(sg | (st << 8)));
-                        if (need) {
-                            const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
-                            const int x0 = st * fg.strip_cols, x1 = std::min(x0 + fg.strip_cols, g.W);
-                            npix += (long long)(y1 - y0) * (x1 - x0);
+                    if (needed.empty() || unneeded.empty()) return LC_OK;          // nothing to skip at this level
+                    for (int lv = 0; lv < pp->nlevels; lv++)
+                        if (pp->levels[lv].n_needed == (int)needed.size()) return LC_OK;   // no looser than the level before it
+                    std::vector<uint32_t> rw;
+                    const size_t nw = bits.size();
+                    for (size_t i = 0; i < nw; i++)
+                        if (rcode[i] | rcode[nw + i] | rcode[2 * nw + i] | rcode[3 * nw + i]) rw.push_back((uint32_t)i);
+                    lc_pipe::SkipLevel &L = pp->levels[pp->nlevels];
+                    int rc2;
+                    if ((rc2 = L.needed.alloc(needed.size())) || (rc2 = L.unneeded.alloc(unneeded.size())) ||
+                        (rc2 = L.ring_words.alloc(rw.size())) || (rc2 = L.ring_code.alloc(rcode.size()))) return rc2;
+                    hipError_t e = hipMemcpy(L.needed.p, needed.data(), needed.size() * 2, hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMemcpy(L.unneeded.p, unneeded.data(), unneeded.size() * 2, hipMemcpyHostToDevice);
+                    if (e == hipSuccess && !rw.empty()) e = hipMemcpy(L.ring_words.p, rw.data(), rw.size() * 4, hipMemcpyHostToDevice);
+                    if (e == hipSuccess) e = hipMemcpy(L.ring_code.p, rcode.data(), rcode.size() * 8, hipMemcpyHostToDevice);
+                    if (e != hipSuccess) return fail(LC_EHIP, "unit list upload failed: %s", hipGetErrorString(e));
+                    L.n_needed = (int)needed.size(); L.n_unneeded = (int)unneeded.size(); L.n_ring_words = (int)rw.size();
+                    L.pixels = npix;
+                    pp->nlevels++;
+                    return LC_OK;
+                };
+                if (fg.nseg_top + fg.nseg_low < 256 && fg.nstrips < 256) {
+                    if ((rc = add_level(cur, code))) { delete pp; return rc; }
+                    if (pp->row_split > 0) {
+                        // the band of rows the ROI spans as the region: ring k = row (first ROI row) - k, all columns
+                        std::vector<uint64_t> band(bits.size(), 0), bcode(4 * bits.size(), 0);
+                        for (int y = pp->row_split; y < H; y++)
+                            for (int tx = 0; tx < TX; tx++) band[(size_t)y * TX + tx] = tx == TX - 1 ? last_mask : ~0ull;
+                        for (int k = 1; k <= NRING; k++) {
+                            const int y = pp->roi_first_row - k;
+                            if (y < 0) break;
+                            for (int tx = 0; tx < TX; tx++)
+                                for (int b = 0; b < 4; b++)
+                                    if (k & (1 << b)) bcode[b * bits.size() + (size_t)y * TX + tx] = tx == TX - 1 ? last_mask : ~0ull;
                         }
+                        if ((rc = add_level(band, bcode))) { delete pp; return rc; }
                     }
-                std::vector<uint32_t> rw;
-                for (size_t i = 0; i < bits.size(); i++)
-                    if (code[i] | code[bits.size() + i] | code[2 * bits.size() + i] | code[3 * bits.size() + i]) rw.push_back((uint32_t)i);
-                if (!needed.empty() && !unneeded.empty() && fg.nseg_top + fg.nseg_low < 256 && fg.nstrips < 256) {
-                    if ((rc = pp->units_needed.alloc(needed.size())) || (rc = pp->units_unneeded.alloc(unneeded.size())) ||
-                        (rc = pp->ring_words.alloc(rw.size())) || (rc = pp->ring_code.alloc(code.size()))) { delete pp; return rc; }
-                    hipError_t e = hipMemcpy(pp->units_needed.p, needed.data(), needed.size() * 2, hipMemcpyHostToDevice);
-                    if (e == hipSuccess) e = hipMemcpy(pp->units_unneeded.p, unneeded.data(), unneeded.size() * 2, hipMemcpyHostToDevice);
-                    if (e == hipSuccess && !rw.empty()) e = hipMemcpy(pp->ring_words.p, rw.data(), rw.size() * 4, hipMemcpyHostToDevice);
-                    if (e == hipSuccess) e = hipMemcpy(pp->ring_code.p, code.data(), code.size() * 8, hipMemcpyHostToDevice);
-                    if (e != hipSuccess) { delete pp; return fail(LC_EHIP, "unit list upload failed: %s", hipGetErrorString(e)); }
-                    pp->n_needed = (int)needed.size(); pp->n_unneeded = (int)unneeded.size(); pp->n_ring_words = (int)rw.size();
-                    pp->roi_skip = true;
-                    pp->classified_pixels = npix;
+                }
+                if (pp->nlevels > 0) {
+                    std::vector<int> one(p.max_batch, 1);
+                    if ((rc = pp->ones.alloc(one.size()))) { delete pp; return rc; }
+                    if (hipMemcpy(pp->ones.p, one.data(), one.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                        delete pp;
+                        return fail(LC_EHIP, "flag upload failed");
+                    }
                 } else {
                     pp->row_split = 0;
                 }
             }
         }
-        if (!pp->roi_skip) {
-            pp->front_rows = front_stream_rows_per_unit(g, p.max_batch, g.H);
-            pp->classified_pixels = (long long)g.W * g.H;
-        }
+        if (pp->nlevels == 0) pp->front_rows = front_stream_rows_per_unit(g, p.max_batch, g.H);
+        pp->frame_pixels = (long long)g.W * g.H;
     }
+
     {
         // All streams have the same priority.  With the post and HoughLinesP streams at high priority their few
         // workgroups were placed ahead of a front kernel's thousands a little sooner (327 k against 320 k frames/s at
@@ -1714,6 +1775,16 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
     if (p.want_segments && s->h_status[2]) pipe->ppht_full_for = 64;   // a frame outgrew half a CU's LDS (see lc_pipe)
+    if (s->level < pipe->nlevels && s->h_status[3]) {                   // frames that needed the full pass after all
+        int redone = 0;
+        for (int i = 0; i < s->nframes; i++) redone += (s->h_rounds[i] >> 30) & 1;
+        const char *ob = getenv("LANECV_SKIP_OFF_BATCHES");         // diagnostics / tests; 0 = never move a level out
+        const int off_batches = ob ? atoi(ob) : 256;
+        if (16 * redone > s->nframes && off_batches > 0 && pipe->level <= s->level) {
+            pipe->level = s->level + 1;
+            pipe->level_hold = off_batches;
+        }
+    }
     if (p.want_segments || p.want_accumulator || p.want_points) {
         if (s->h_status[0])
             return fail(LC_ECAP, "a frame holds more edge points than the pipeline keeps per frame (%d): its point list, accumulator and "
@@ -1814,7 +1885,7 @@ int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_to
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
     int mx = 0, tot = 0;
-    for (int i = 0; i < s->nframes; i++) { mx = std::max(mx, s->h_rounds[i]); tot += s->h_rounds[i]; }
+    for (int i = 0; i < s->nframes; i++) { const int r = s->h_rounds[i] & 0x3FFFFFFF; mx = std::max(mx, r); tot += r; }
     if (rounds_max) *rounds_max = mx;
     if (rounds_total) *rounds_total = tot;
     return LC_OK;
@@ -1826,10 +1897,11 @@ int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
     if (first_row) *first_row = pipe->row_split;
-    if (pixels_classified) *pixels_classified = pipe->classified_pixels;
+    if (pixels_classified) *pixels_classified = s->level < pipe->nlevels ? pipe->levels[s->level].pixels : pipe->frame_pixels;
     if (frames_redone) {
         *frames_redone = 0;
-        if (pipe->roi_skip && s->nframes > 0) {
+        if (pipe->nlevels > 0 && s->level >= pipe->nlevels) *frames_redone = s->nframes;     // classified in full from the start
+        else if (pipe->nlevels > 0 && s->nframes > 0) {
             std::vector<int> redo(s->nframes);
             HIP_TRY(hipMemcpy(redo.data(), s->w.redo.p, sizeof(int) * s->nframes, hipMemcpyDeviceToHost));
             for (int v : redo) *frames_redone += v != 0;

@@ -134,7 +134,8 @@ void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *pla
 // ring_words: indices of the plane words that hold ring pixels; code[b]: bit plane b of the ring number (0 = no ring).
 // status (may be null): word 3 is set if any frame was flagged.
 void launch_ring_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, const uint32_t *ring_words,
-                       int nring_words, const uint64_t *code, int *redo, int *status, hipStream_t st);
+                       int nring_words, const uint64_t *code, int *redo, int *status, hipStream_t st, int *rounds = nullptr);
+// rounds (may be null): the per-frame words launch_hysteresis wrote; bit 30 is set in those of the frames flagged
 // roi_bits: one plane shared by all frames, or nullptr
 // prevbits (may be null): the masked bits of the previous call on the same masked_out / rowplane buffers, all
 // zero before the first (like those buffers); with it, and without edges_out, only what changed is written

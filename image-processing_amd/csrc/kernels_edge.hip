@@ -380,7 +380,8 @@ __device__ __forceinline__ void stF(uint32_t *p, uint32_t v) {
 // the rounds of one frame, run by the HC_THREADS threads of a workgroup; `any` is a word of LDS
 __device__ __forceinline__ void hysteresis_frame(const Geo &g, int f, uint64_t *__restrict__ planeS,
                                                  const uint64_t *__restrict__ planeW, uint32_t *__restrict__ wakeA,
-                                                 uint32_t *__restrict__ wakeB, int *__restrict__ rounds_out, int &any) {
+                                                 uint32_t *__restrict__ wakeB, int *__restrict__ rounds_out, int &any,
+                                                 const int keep_bits = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = g.TX * g.TY;
     uint32_t *cur = wakeA + (size_t)f * ntile, *nxt = wakeB + (size_t)f * ntile;   // nxt starts all zero
@@ -413,7 +414,7 @@ __device__ __forceinline__ void hysteresis_frame(const Geo &g, int f, uint64_t *
         uint32_t *tmp = cur; cur = nxt; nxt = tmp;
         rounds++;
     }
-    if (tid == 0 && rounds_out) rounds_out[f] = rounds;
+    if (tid == 0 && rounds_out) rounds_out[f] = rounds | keep_bits;
 }
 
 __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__restrict__ planeS,
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__re
     // (the status words are raised by the kernels behind this one; a launch for a few frames only is such a kernel)
     if (status && !only_frames && blockIdx.x == 0 && threadIdx.x == 0) status[0] = status[1] = status[2] = status[3] = 0;
     if (only_frames && only_frames[blockIdx.x] == 0) return;
-    hysteresis_frame(g, blockIdx.x, planeS, planeW, wakeA, wakeB, rounds_out, any);
+    // (a second pass over flagged frames keeps the mark k_ring_check left in the rounds word)
+    hysteresis_frame(g, blockIdx.x, planeS, planeW, wakeA, wakeB, rounds_out, any, only_frames ? 0x40000000 : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -436,11 +438,11 @@ __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__re
 // them through 8-neighbours in the list; only if the flood arrives in ring 15 (or the list overflows) is the frame
 // classified again in full.
 // ---------------------------------------------------------------------------
-constexpr int RING_LIST = 512;
+constexpr int RING_LIST = 256, RING_ROUNDS = 48;   // beyond either the frame is classified in full rather than looked at longer
 __global__ __launch_bounds__(64) void k_ring_check(Geo g, const uint64_t *__restrict__ planeS, const uint64_t *__restrict__ planeW,
                                                    const uint32_t *__restrict__ ring_words, int nring_words,
                                                    const uint64_t *__restrict__ code, int *__restrict__ redo,
-                                                   int *__restrict__ status) {
+                                                   int *__restrict__ status, int *__restrict__ rounds) {
     __shared__ uint32_t px[RING_LIST];        // x | y << 13 | ring << 26 | reached << 31
     __shared__ int count;
     const int f = blockIdx.x, lane = threadIdx.x;
@@ -477,7 +479,8 @@ __global__ __launch_bounds__(64) void k_ring_check(Geo g, const uint64_t *__rest
     overflow = n > RING_LIST;
     bool arrived = false;
     if (!overflow) {
-        for (;;) {          // at most n rounds: every round but the last reaches a new pixel
+        bool settled = false;
+        for (int round = 0; round < RING_ROUNDS && !settled; round++) {
             bool changed = false;
             for (int i = lane; i < n; i += 64) {
                 const uint32_t p = px[i];
@@ -491,14 +494,16 @@ __global__ __launch_bounds__(64) void k_ring_check(Geo g, const uint64_t *__rest
                 if (hit) { px[i] = p | 0x80000000u; changed = true; }
             }
             __syncthreads();
-            if (__ballot(changed) == 0) break;
+            settled = __ballot(changed) == 0;
         }
+        arrived = !settled;                            // still spreading after RING_ROUNDS: do not look longer
         for (int i = lane; i < n; i += 64) arrived |= (px[i] >> 31) && ((px[i] >> 26) & 15) == 15;
     }
     const bool bad = overflow || __ballot(arrived) != 0;
     if (lane == 0) {
         redo[f] = bad ? 1 : 0;
-        if (bad && status) status[3] = 1;        // (a plain store: the words may live in host memory)
+        if (bad && status) status[3] = 1;        // (plain stores: the words may live in host memory)
+        if (bad && rounds) rounds[f] |= 0x40000000;   // the host counts the frames redone from this bit of the rounds word
     }
 }
 
@@ -696,8 +701,8 @@ void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *pla
 }
 
 void launch_ring_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, const uint32_t *ring_words,
-                       int nring_words, const uint64_t *code, int *redo, int *status, hipStream_t st) {
-    hipLaunchKernelGGL(k_ring_check, dim3(nframes), dim3(64), 0, st, g, planeS, planeW, ring_words, nring_words, code, redo, status);
+                       int nring_words, const uint64_t *code, int *redo, int *status, hipStream_t st, int *rounds) {
+    hipLaunchKernelGGL(k_ring_check, dim3(nframes), dim3(64), 0, st, g, planeS, planeW, ring_words, nring_words, code, redo, status, rounds);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,

@@ -1250,6 +1250,8 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
     // kernel decides, per frame) is flagged.
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
     if (lds_bytes <= 0 || lds_bytes > PPHT_LDS_MAX) lds_bytes = PPHT_LDS_MAX;
+    static const char *half_env = getenv("LANECV_PPHT_HALF_KB");       // diagnostics: another size for the shared-CU launches
+    if (half_env && lds_bytes == PPHT_LDS_HALF) lds_bytes = atoi(half_env) * 1024;
     const int lds_points = std::min(rng_len, LDS_BIAS - 1);
     static LdsOptIn optin8, optin4;
     static const char *wv_env = getenv("LANECV_PPHT_WAVES");           // diagnostics: 4 or 8 whatever the LDS size

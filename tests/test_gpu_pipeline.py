@@ -329,7 +329,7 @@ def test_temporaries_stay_alive_per_slot(oracle):
     pipe.close()
 
 
-def test_rows_above_the_roi_are_skipped_exactly(oracle):
+def test_rows_above_the_roi_are_skipped_exactly(oracle, monkeypatch):
     """A pipeline whose ROI begins far down the frame classifies only the rows from a little above the ROI: per frame
     it proves that nothing above can reach the ROI through weak pixels, and classifies the frame again from row 0
     where it cannot.  Road frames must take the short way, frames built to need the rows above must be caught
@@ -337,6 +337,7 @@ def test_rows_above_the_roi_are_skipped_exactly(oracle):
     saw such a frame must be clean again for the next batch."""
     from lanecv import synth, _abi
     from lanecv.pipeline import LanePipeline, Recipe
+    monkeypatch.setenv("LANECV_SKIP_OFF_BATCHES", "0")      # stay at the tightest level whatever the share of frames redone
     w, h = 960, 540
     rec = Recipe.north_star(w, h)
     pipe = LanePipeline(w, h, rec, max_batch=6, nslots=2, seg_capacity=512)
@@ -365,6 +366,47 @@ def test_rows_above_the_roi_are_skipped_exactly(oracle):
         segs = pipe.collect(0)
         masked, acc = pipe.read(0, _abi.BUF_MASKED), pipe.read(0, _abi.BUF_ACC)
         assert pipe.row_skip(0)[1] == want_redone[b], b
+        for i, f in enumerate(frames):
+            r = _oracle_frame(oracle, f, rec, pipe.roi)
+            assert (masked[i] == r["masked"]).all(), (b, i)
+            assert (acc[i] == r["acc"]).all(), (b, i)
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (b, i)
+    pipe.close()
+
+
+def test_roi_skipping_switches_off_and_on_again(oracle, monkeypatch):
+    """A batch in which more than a quarter of the frames needed all units after all switches the ROI scheme off for a
+    number of batches (here 2 instead of 256), which are classified in full from the start; the slot then skips again,
+    after the plane rows such batches left outside the needed units have been cleared.  Results never change."""
+    monkeypatch.setenv("LANECV_SKIP_OFF_BATCHES", "2")
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h = 960, 540
+    rec = Recipe.north_star(w, h)
+    pipe = LanePipeline(w, h, rec, max_batch=4, nslots=1, seg_capacity=512)
+    g = np.full((h, w), 60, np.int32)
+    g[:100, w // 2 + 40:] += 120
+    g[100:, w // 2 + 40:] += 60
+    faint = np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+    noise = synth.adversarial_frames(w, h)["noise"]
+    road = [synth.synth_road(w, h, seed=43, t=t) for t in range(4)]
+    batches = [np.stack([faint, road[0], faint, road[1]]),     # half of it redone at level 0 (units near the ROI): one level out
+               np.stack([faint, noise, faint, faint]),         # level 1 (all rows from above the ROI down): all redone, out again
+               np.stack([noise, road[2], road[3], road[0]]),   # in full from the start
+               np.stack(road),                                  # in full
+               np.stack(road[::-1]),                            # level 1 again: the rows above must be clean
+               np.stack(road),                                  # level 1
+               np.stack(road[::-1]),                            # level 0 again: the units away from the ROI must be clean
+               np.stack(road)]
+    want_redone = [2, 4, 4, 4, 0, 0, 0, 0]
+    want_pixels_less = [True, True, False, False, True, True, True, True]
+    for b, frames in enumerate(batches):
+        pipe.submit(0, frames)
+        segs = pipe.collect(0)
+        masked, acc = pipe.read(0, _abi.BUF_MASKED), pipe.read(0, _abi.BUF_ACC)
+        first, pixels, redone = pipe.roi_skip(0)
+        assert redone == want_redone[b] and (pixels < w * h) == want_pixels_less[b], (b, first, pixels, redone)
         for i, f in enumerate(frames):
             r = _oracle_frame(oracle, f, rec, pipe.roi)
             assert (masked[i] == r["masked"]).all(), (b, i)
