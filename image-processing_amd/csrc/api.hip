@@ -45,6 +45,7 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool owned = true;      // false: a slice of another buffer (alias), not freed here
     int alloc(size_t count) {
         release();
         if (count == 0) count = 1;
@@ -53,13 +54,14 @@ struct DevBuf {
         n = count;
         return LC_OK;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
+    void alias(T *base, size_t count) { release(); p = base; n = count; owned = false; }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; o.owned = true; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; o.owned = true; }
         return *this;
     }
     ~DevBuf() { release(); }
@@ -1081,6 +1083,9 @@ struct Slot {
     bool busy = false, timed = false;
     int level = 0;                // ROI-scheme level of the batch in flight (or last); the pipeline's nlevels = classified in full
     int planes_level = 0;         // loosest level a batch of this slot ran at since its planes were last cleared down
+    int group = 0, gpos = 0;      // group of slots whose HoughLinesP runs as one launch, and the slot's place in it
+    bool lines_pending = false;   // the batch's points are queued, its HoughLinesP launch is not yet
+    int *h_gstatus = nullptr;     // status words the group's HoughLinesP launch raises (the slot's own without groups)
     // pinned host mirror of the slot's result block
     int32_t *h_res = nullptr;
     bool zero_copy = false;       // the kernels write the result block straight into h_res (mapped pinned memory)
@@ -1178,6 +1183,23 @@ struct lc_pipe {
     // that slot queues it at once.  defer_after: 0 = never defer, 1 = behind the front end, 2 = behind hysteresis.
     int deferred = -1;
     int defer_after = 1;
+    // Batches that leave most CUs free (HoughLinesP is one workgroup per frame) do not get a HoughLinesP launch each:
+    // `group_size` consecutive slots form a group whose launch covers all their frames at once, queued when the
+    // group's last slot has been submitted or one of its slots is waited for.  The buffers that launch indexes by frame
+    // (point lists, counts, bit planes, accumulators, segments) are slices of one allocation per group, a slot's
+    // frames following the previous slot's full capacity; 1 = no grouping.
+    struct Group {
+        DevBuf<uint32_t> nz;
+        DevBuf<int> npoints, fallback;
+        DevBuf<uint64_t> rowplane;
+        DevBuf<int32_t> acc_full, acc_ppht;
+        int32_t *h_res = nullptr;          // pinned: [segcount G*B][rounds G*B][status 8*G][group status 8][segments G*B*cap*4]
+        int32_t *d_res = nullptr;          // the same block as the GPU addresses it
+        int *h_gstatus = nullptr, *d_gstatus = nullptr;
+        std::vector<int> pending;          // slots with points queued and HoughLinesP not yet, in submission order
+    };
+    int group_size = 1;
+    std::vector<Group> groups;
     std::vector<Slot> slots;
 };
 
@@ -1186,6 +1208,7 @@ namespace {
 enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END, EV_ESTART, EV_LSTART, EV_VSTART };
 
 void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after);
+void flush_group(lc_pipe *pp, int g);
 
 void enqueue_back(lc_pipe *pp, Slot &s) {
     Work &w = s.w;
@@ -1215,8 +1238,63 @@ void enqueue_back(lc_pipe *pp, Slot &s) {
     if (p.want_accumulator && !vote_fused)
         launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, nullptr, es);
     if (!vote_fused) (void)hipEventRecord(s.ev[EV_VOTE], es);
+    if (p.want_segments && pp->group_size > 1) {
+        // grouped slots: the HoughLinesP launch waits for the group's last slot (or for a wait on one of its slots).
+        // Frames of the slot's capacity beyond this batch must read as empty to that launch.
+        if (n < p.max_batch) (void)hipMemsetAsync(w.npoints.p + n, 0, sizeof(int) * (size_t)(p.max_batch - n), es);
+        lc_pipe::Group &G = pp->groups[s.group];
+        G.pending.push_back((int)(&s - &pp->slots[0]));
+        s.lines_pending = true;
+        const int first = s.group * pp->group_size, gs = std::min(pp->group_size, (int)pp->slots.size() - first);
+        if ((int)G.pending.size() >= gs) flush_group(pp, s.group);
+        return;
+    }
     if (p.want_segments && pp->st_lines != es && pp->defer_after && pp->slots.size() > 1) pp->deferred = (int)(&s - &pp->slots[0]);
     else enqueue_lines(pp, s, nullptr);
+}
+
+// One HoughLinesP launch for the slots of a group whose points are queued: their frames lie back to back in the
+// group's buffers (slot j at frame j * max_batch), the launch covers them all.
+void flush_group(lc_pipe *pp, int g) {
+    lc_pipe::Group &G = pp->groups[g];
+    if (G.pending.empty()) return;
+    const lc_pipe_params &p = pp->p;
+    const int first = g * pp->group_size, m = (int)G.pending.size();
+    bool prefix = true;
+    for (int i = 0; i < m; i++) prefix = prefix && G.pending[i] == first + i;
+    if (!prefix) {      // slots used out of order: a launch each
+        for (int k : G.pending) { pp->slots[k].lines_pending = false; enqueue_lines(pp, pp->slots[k], nullptr); }
+        G.pending.clear();
+        return;
+    }
+    Slot &lead = pp->slots[first];
+    Work &w = lead.w;
+    const int n_total = (m - 1) * p.max_batch + pp->slots[first + m - 1].nframes;
+    const bool vote_fused = p.want_accumulator && p.want_segments && pp->fuse_vote;
+    const unsigned turn = pp->lines_turn++ % (unsigned)(1 + pp->st_lines_more.size());
+    hipStream_t ls = turn ? pp->st_lines_more[turn - 1] : pp->st_lines;
+    for (int i = 0; i < m; i++) {
+        Slot &s = pp->slots[first + i];
+        if (ls != pp->st_post) (void)hipStreamWaitEvent(ls, s.ev[(p.want_accumulator && !vote_fused) ? EV_VOTE : EV_POINTS], 0);
+    }
+    for (int k = 0; k < 8; k++) G.h_gstatus[k] = 0;     // (every slot of the group has been waited for since the last launch)
+    for (int i = 0; i < m; i++) (void)hipEventRecord(pp->slots[first + i].ev[EV_LSTART], ls);
+    const bool fast = launch_ppht_fast(w.g, n_total, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
+                                       p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, G.d_gstatus,
+                                       w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls,
+                                       (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false,
+                                       2 * n_total > pp->cu_count ? 0 : 8);
+    if (pp->ppht_full_for > 0) pp->ppht_full_for--;
+    launch_ppht_general(w.g, n_total, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
+                        p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, G.d_gstatus,
+                        fast ? w.fallback.p : nullptr, ls, vote_fused ? w.acc_full.p : nullptr);
+    for (int i = 0; i < m; i++) {
+        Slot &s = pp->slots[first + i];
+        (void)hipEventRecord(s.ev[EV_LINES], ls);
+        s.end_ev = EV_LINES;
+        s.lines_pending = false;
+    }
+    G.pending.clear();
 }
 
 // HoughLinesP step and the copy of the batch's results; `after` (may be null) is a later batch's event to start behind
@@ -1678,6 +1756,63 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
             s.zero_copy = true;
         }
     }
+    for (Slot &s : pp->slots) s.h_gstatus = s.h_status;
+    {
+        // groups of slots with one HoughLinesP launch (see lc_pipe::Group): for batches that leave CUs free, when there
+        // are slots enough to fill one group while another one's launch runs
+        bool all_zero_copy = true;
+        for (Slot &s : pp->slots) all_zero_copy = all_zero_copy && s.zero_copy;
+        const char *ge = getenv("LANECV_NO_GROUPS");
+        int G = 1;
+        if (p.want_segments && all_zero_copy && !ge && 2 * p.max_batch <= pp->cu_count && p.nslots >= 4)
+            G = std::max(1, std::min(p.nslots / 2, pp->cu_count / p.max_batch));
+        if (G > 1) {
+            pp->group_size = G;
+            const int B = p.max_batch, segcap = std::max(p.seg_capacity, 1);
+            const size_t words = pp->g.rowplane_words();
+            pp->groups.resize((p.nslots + G - 1) / G);
+            for (size_t gi = 0; gi < pp->groups.size(); gi++) {
+                lc_pipe::Group &grp = pp->groups[gi];
+                const int first = (int)gi * G, gs = std::min(G, p.nslots - first);
+                Work &w0 = pp->slots[first].w;
+                const size_t accn = (size_t)w0.hg.numangle * w0.hg.numrho, cap = (size_t)w0.nz_cap, nfr = (size_t)gs * B;
+                if ((rc = grp.nz.alloc(nfr * cap)) || (rc = grp.npoints.alloc(nfr)) || (rc = grp.fallback.alloc(nfr)) ||
+                    (rc = grp.rowplane.alloc(nfr * words)) || (rc = grp.acc_ppht.alloc(nfr * accn)) ||
+                    (p.want_accumulator && (rc = grp.acc_full.alloc(nfr * accn)))) { lc_pipe_destroy(pp); return rc; }
+                HIP_TRY(hipMemset(grp.rowplane.p, 0, sizeof(uint64_t) * nfr * words));
+                HIP_TRY(hipMemset(grp.npoints.p, 0, sizeof(int) * nfr));
+                const size_t head = 2 * nfr + 8 * (size_t)gs + 8, ints = head + nfr * segcap * 4;
+                void *hp = nullptr, *dp = nullptr;
+                if (hipHostMalloc(&hp, sizeof(int32_t) * ints, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                    hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess || !dp) {
+                    lc_pipe_destroy(pp);
+                    return fail(LC_EHIP, "pinned result block of a slot group failed");
+                }
+                grp.h_res = (int32_t *)hp; grp.d_res = (int32_t *)dp;
+                memset(grp.h_res, 0, sizeof(int32_t) * head);
+                grp.h_gstatus = grp.h_res + 2 * nfr + 8 * (size_t)gs;
+                grp.d_gstatus = grp.d_res + 2 * nfr + 8 * (size_t)gs;
+                for (int j = 0; j < gs; j++) {
+                    Slot &s = pp->slots[first + j];
+                    Work &w = s.w;
+                    const size_t fo = (size_t)j * B;      // the slot's first frame in the group's buffers
+                    w.nz.alias(grp.nz.p + fo * cap, (size_t)B * cap);
+                    w.npoints.alias(grp.npoints.p + fo, B);
+                    w.fallback.alias(grp.fallback.p + fo, B);
+                    w.rowplane.alias(grp.rowplane.p + fo * words, (size_t)B * words);
+                    w.acc_ppht.alias(grp.acc_ppht.p + fo * accn, (size_t)B * accn);
+                    if (p.want_accumulator) w.acc_full.alias(grp.acc_full.p + fo * accn, (size_t)B * accn);
+                    if (s.h_res) { (void)hipHostFree(s.h_res); s.h_res = nullptr; }
+                    s.group = (int)gi; s.gpos = j;
+                    s.h_segcount = grp.h_res + fo; s.h_rounds = grp.h_res + nfr + fo; s.h_status = grp.h_res + 2 * nfr + 8 * (size_t)j;
+                    s.h_seg = grp.h_res + head + fo * segcap * 4;
+                    s.h_gstatus = grp.h_gstatus;
+                    w.r_segcount = grp.d_res + fo; w.r_rounds = grp.d_res + nfr + fo; w.r_status = grp.d_res + 2 * nfr + 8 * (size_t)j;
+                    w.r_seg = grp.d_res + head + fo * segcap * 4;
+                }
+            }
+        }
+    }
     // the buffers were cleared with hipMemset, which may still be running on the null stream, and the pipeline's
     // streams do not wait for that stream: nothing may be submitted before the clears have landed
     {
@@ -1692,6 +1827,7 @@ int lc_pipe_destroy(lc_pipe *pipe) {
     if (!pipe) return LC_OK;
     (void)hipSetDevice(pipe->ctx->device);
     if (pipe->deferred >= 0 && pipe->st_lines) { enqueue_lines(pipe, pipe->slots[pipe->deferred], nullptr); pipe->deferred = -1; }
+    if (pipe->st_lines) for (size_t g = 0; g < pipe->groups.size(); g++) flush_group(pipe, (int)g);
     if (pipe->st_up) (void)hipStreamSynchronize(pipe->st_up);
     if (pipe->st_edge) (void)hipStreamSynchronize(pipe->st_edge);
     if (pipe->st_lines) (void)hipStreamSynchronize(pipe->st_lines);
@@ -1700,6 +1836,9 @@ int lc_pipe_destroy(lc_pipe *pipe) {
     for (Slot &s : pipe->slots) {
         for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
         if (s.h_res) (void)hipHostFree(s.h_res);
+    }
+    for (lc_pipe::Group &G : pipe->groups) {
+        if (G.h_res) (void)hipHostFree(G.h_res);
     }
     if (pipe->st_lines && pipe->st_lines != pipe->st_edge) (void)hipStreamDestroy(pipe->st_lines);
     if (pipe->st_edge) (void)hipStreamDestroy(pipe->st_edge);
@@ -1743,6 +1882,7 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
     if (pipe->deferred == slot) { enqueue_lines(pipe, *s, nullptr); pipe->deferred = -1; }
+    if (s->lines_pending) flush_group(pipe, s->group);
     // The wait polls the batch's last event and gives up after LANECV_WAIT_TIMEOUT_S seconds (default 120; 0 = block
     // in hipEventSynchronize for ever) with a report of which of the pipeline's events have fired, per slot, in the
     // order of the EV_ enumeration: a pipeline whose streams starve each other (more streams in the process than
@@ -1774,7 +1914,7 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     }
     s->busy = false;
     const lc_pipe_params &p = pipe->p;
-    if (p.want_segments && s->h_status[2]) pipe->ppht_full_for = 64;   // a frame outgrew half a CU's LDS (see lc_pipe)
+    if (p.want_segments && (s->h_status[2] | s->h_gstatus[2])) pipe->ppht_full_for = 64;   // a frame outgrew half a CU's LDS (see lc_pipe)
     if (s->level < pipe->nlevels && s->h_status[3]) {                   // frames that needed the full pass after all
         int redone = 0;
         for (int i = 0; i < s->nframes; i++) redone += (s->h_rounds[i] >> 30) & 1;
@@ -1786,10 +1926,10 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         }
     }
     if (p.want_segments || p.want_accumulator || p.want_points) {
-        if (s->h_status[0])
+        if (s->h_status[0] | s->h_gstatus[0])
             return fail(LC_ECAP, "a frame holds more edge points than the pipeline keeps per frame (%d): its point list, accumulator and "
                         "segments are incomplete", s->w.nz_cap);
-        if (s->h_status[1])
+        if (s->h_status[1] | s->h_gstatus[1])
             return fail(LC_EINVAL, "HoughLinesP: a vote fell outside the accumulator (the angle table does not fit the image size)");
     }
     if (p.want_segments) {
