@@ -175,7 +175,10 @@ int lds_atomic_probe(int run, bool returning, int blocks, int iters, int *sink, 
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
-                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes = 0, bool only_flagged = false, int waves = 0);
+                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes = 0, bool only_flagged = false, int waves = 0,
+                      int status_frames = 0);
+// status_frames: 0 = one block of status words for the launch; n = frames [k n, (k + 1) n) raise status + 8 k (a launch
+// over the batches of several pipeline slots, each with status words of its own)
 // waves: 8 or 4 wavefronts per frame (0: 4 with ppht_lds_half(), else 8).  Four is for launches that fill every CU twice
 // over; a batch that leaves CUs free is better served by eight even with half the LDS.
 // lds_bytes: dynamic LDS per frame (0 = the most a CU gives one workgroup); with ppht_lds_half() two frames share a
@@ -184,7 +187,7 @@ int ppht_lds_half();
 void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                          const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
                          int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, const int *flags,
-                         hipStream_t st, int32_t *vote_acc = nullptr);   // vote_acc: also the full-vote accumulator of the frames flagged with bit 1
+                         hipStream_t st, int32_t *vote_acc = nullptr, int status_frames = 0);   // vote_acc: also the full-vote accumulator of the frames flagged with bit 1
 // polygons
 struct PolyEdgeDev { int y0, y1; long long x, dx; };
 struct LineDev { int x0, y0, count, vert, dmaj, dmin, dmajor_len, dminor_len; };

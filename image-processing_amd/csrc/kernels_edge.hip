@@ -672,10 +672,9 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
                   hipStream_t st, const GateDev *gate, const int *tab, uint8_t *gate_gray, uint8_t *rowflags, bool dec3,
                   int rows_per_unit, const FrontSplit *split) {
     static const char *force_tiled = getenv("LANECV_FRONT_TILED");       // diagnostics: use the tiled kernel everywhere
-    static const char *rows_env = getenv("LANECV_FRONT_ROWS");           // tuning: rows per streaming unit
     if (in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1')) {
         launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, wake, gray_out, blur_out,
-                            rows_env ? atoi(rows_env) : rows_per_unit, gate, tab, st, rowflags, dec3, split);
+                            rows_per_unit, gate, tab, st, rowflags, dec3, split);
         return;
     }
     if (gate && in_kind == 1) {   // gated gray first, then the tiled kernel on that gray image

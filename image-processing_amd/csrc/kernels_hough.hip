@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, int nframes, uint32
                                                       int line_gap, int32_t *__restrict__ seg_all, int seg_cap,
                                                       int *__restrict__ seg_count, int *__restrict__ status,
                                                       const int *__restrict__ fallback, int32_t *__restrict__ vote_acc,
-                                                      int vote_apg) {
+                                                      int vote_apg, int status_frames) {
     extern __shared__ int lacc_vote[];
     const int G = gridDim.x;
     for (int base = blockIdx.x; base < nframes; base += G * 64) {
@@ -743,7 +743,8 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, int nframes, uint32
             const int f = base + G * __builtin_ctzll(todo);
             todo &= todo - 1;
             ppht_general_frame(f, fallback ? fallback[f] : 3, lacc_vote, g, nz_all, nz_cap, npoints, rowplane, tab, numangle, numrho,
-                               acc_all, threshold, line_length, line_gap, seg_all, seg_cap, seg_count, status, vote_acc, vote_apg);
+                               acc_all, threshold, line_length, line_gap, seg_all, seg_cap, seg_count,
+                               status + (status_frames ? 8 * (f / status_frames) : 0), vote_acc, vote_apg);
             __syncthreads();
         }
         if (!fallback) break;
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
                                                    int32_t *__restrict__ seg_all, int seg_cap, int *__restrict__ seg_count,
                                                    int *__restrict__ status, int *__restrict__ fallback, int lds_points,
                                                    const uint32_t *__restrict__ rng_out, int lds_bytes,
-                                                   int32_t *__restrict__ acc_full, int only_flagged) {
+                                                   int32_t *__restrict__ acc_full, int only_flagged, int status_frames) {
     constexpr int PPHT_THREADS = 64 * PPHT_WAVES;
     extern __shared__ __align__(16) uint32_t lds32[];
     __shared__ int progress;
@@ -775,6 +776,8 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     __shared__ int a_rmin[64];
     __shared__ AngleEntry s_tab[64];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // one launch may cover the batches of several pipeline slots: every status_frames frames have status words of their own
+    if (status_frames) status += 8 * (f / status_frames);
 #ifdef LC_STAMPS
     if (f == 0 && lane == 0) g_simd[wave] = __builtin_amdgcn_s_getreg(2308);
     const long long t_kernel0 = STAMP();
@@ -1226,8 +1229,7 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
     // workgroups fill a CU's wave slots), so that a workgroup's pass over the frame's points serves more angles;
     // 32 KiB was slower (0.054 against 0.040 ms for 256 1080p frames), 8 KiB too (0.079)
     const int budget = 16 * 1024;
-    static const char *vb_env = getenv("LANECV_VOTE_LDS_KB");
-    const int apg = flags ? vote_apg(numangle, numrho, groups) : vote_apg(numangle, numrho, groups, vb_env ? atoi(vb_env) * 1024 : budget);
+    const int apg = flags ? vote_apg(numangle, numrho, groups) : vote_apg(numangle, numrho, groups, budget);
     size_t lds = (size_t)apg * (numrho + 1) * 4;
     static LdsOptIn optin;
     (void)optin.ensure(reinterpret_cast<const void *>(k_vote), lds);
@@ -1245,13 +1247,12 @@ int ppht_lds_half() { return PPHT_LDS_HALF; }
 bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
-                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged, int waves) {
+                      int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged, int waves,
+                      int status_frames) {
     // points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not fit lds_bytes (the
     // kernel decides, per frame) is flagged.
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
     if (lds_bytes <= 0 || lds_bytes > PPHT_LDS_MAX) lds_bytes = PPHT_LDS_MAX;
-    static const char *half_env = getenv("LANECV_PPHT_HALF_KB");       // diagnostics: another size for the shared-CU launches
-    if (half_env && lds_bytes == PPHT_LDS_HALF) lds_bytes = atoi(half_env) * 1024;
     const int lds_points = std::min(rng_len, LDS_BIAS - 1);
     static LdsOptIn optin8, optin4;
     static const char *wv_env = getenv("LANECV_PPHT_WAVES");           // diagnostics: 4 or 8 whatever the LDS size
@@ -1260,12 +1261,12 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
         if (optin4.ensure(reinterpret_cast<const void *>(k_ppht_fast<4>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
         hipLaunchKernelGGL(k_ppht_fast<4>, dim3(nframes), dim3(256), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                           lds_bytes, acc_full, only_flagged ? 1 : 0);
+                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames);
     } else {
         if (optin8.ensure(reinterpret_cast<const void *>(k_ppht_fast<8>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
         hipLaunchKernelGGL(k_ppht_fast<8>, dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                           lds_bytes, acc_full, only_flagged ? 1 : 0);
+                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames);
     }
     return true;
 }
@@ -1273,7 +1274,7 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
 void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *npoints, uint64_t *rowplane,
                          const AngleEntry *tab, int numangle, int numrho, int32_t *acc, int threshold, int line_length,
                          int line_gap, int32_t *seg, int seg_cap, int *seg_count, int *status, const int *flags,
-                         hipStream_t st, int32_t *vote_acc) {
+                         hipStream_t st, int32_t *vote_acc, int status_frames) {
     int groups, apg = 0;
     size_t lds = 0;
     if (vote_acc) {
@@ -1284,7 +1285,7 @@ void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int
     }
     hipLaunchKernelGGL(k_ppht_general, dim3(flags ? std::min(nframes, 16) : nframes), dim3(256), lds, st, g, nframes, nz, nz_cap, npoints,
                        rowplane, tab, numangle, numrho, acc, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags,
-                       vote_acc, apg);
+                       vote_acc, apg, status_frames);
 }
 
 #ifdef LC_STAMPS

@@ -1,0 +1,145 @@
+// The batched pipeline behind lc_pipe_*: a slot's buffers and events, the pipeline object, and what pipe_create.hip
+// (set-up) and pipe_run.hip (submit / wait / read) share.
+#pragma once
+#include "host.h"
+
+using lanecv::Geo;
+using lanecv::GateDev;
+using lanecv::FrontSplit;
+
+// ---------------------------------------------------------------------------
+struct Slot {
+    Work w;
+    hipEvent_t ev[12] = {};
+    int nframes = 0;
+    const uint8_t *input = nullptr;   // device pointer of the frames of the batch in flight
+    size_t input_bytes = 0;
+    bool busy = false, timed = false;
+    int level = 0;                // ROI-scheme level of the batch in flight (or last); the pipeline's nlevels = classified in full
+    int planes_level = 0;         // loosest level a batch of this slot ran at since its planes were last cleared down
+    int group = 0, gpos = 0;      // group of slots whose HoughLinesP runs as one launch, and the slot's place in it
+    bool lines_pending = false;   // the batch's points are queued, its HoughLinesP launch is not yet
+    // pinned host mirror of the slot's result block
+    int32_t *h_res = nullptr;
+    bool zero_copy = false;       // the kernels write the result block straight into h_res (mapped pinned memory)
+    int end_ev = 0;               // the event that marks the batch complete (index into ev)
+    int *h_rounds = nullptr, *h_status = nullptr, *h_segcount = nullptr;
+    int32_t *h_seg = nullptr;
+};
+
+struct lc_pipe {
+    lc_ctx *ctx = nullptr;
+    lc_pipe_params p{};
+    Geo g{};
+    int low = 0, high = 0, line_length = 0, line_gap = 0;
+    DevBuf<uint64_t> roi_bits;
+    bool has_roi = false;
+    bool has_gate = false;        // colour gate in front of the gray conversion
+    GateDev gate{};
+    DevBuf<int> gate_tab;     // gate_tables_host: the HSV reciprocal tables and this gate's s/v intervals
+    // cv2.resize in front of everything: submitted frames are src_w x src_h, the pipeline works on width x height
+    bool resizes = false, resize_area2 = false, resize_dec3 = false;
+    int src_w = 0, src_h = 0;
+    size_t src_frame_bytes = 0;   // bytes of one submitted frame
+    // the reduction by exactly three is read by the front kernel itself (no resized frame exists then): without
+    // intermediates, without the colour gate, widths the streaming kernel takes
+    bool fused_dec3() const {
+        return resizes && resize_dec3 && !p.keep_intermediates && !has_gate && front_stream_supported(g) && !getenv("LANECV_FRONT_TILED") &&
+               !getenv("LANECV_NO_FUSED_RESIZE");
+    }
+    DevBuf<int> resize_tab;
+    // A pipeline owns three or four streams of equal priority (more HoughLinesP streams for small batches, below),
+    // whatever its number of slots; a slot is a set of buffers and events.  HIP maps streams onto a few hardware
+    // queues, so the count stays small, and the waits between streams run one way only -- st_up -> st_edge ->
+    // st_post -> st_lines.
+    //   st_up     host-to-device copies of submitted frames (created by the first host submit).
+    //   st_edge   the front kernels (and the leading resize) of all slots, in submission order, back to back.
+    //             They fill the GPU by themselves, so two of them gain nothing from running side by side.
+    //   st_post   the short latency-bound kernels behind a front kernel: hysteresis, finalize, compaction (and the
+    //             vote kernel of accumulator-only recipes); with a single slot it is st_edge itself.
+    //   st_lines  HoughLinesP and the copy of the batch's results.
+    hipStream_t st_up = nullptr, st_edge = nullptr, st_post = nullptr, st_lines = nullptr;
+    // More HoughLinesP streams for small batches: the kernel is one sequential workgroup per frame that takes a CU
+    // for itself, so a batch of 32 frames leaves 7/8 of the chip to whatever may run beside it -- and on a single
+    // stream that is never another batch's HoughLinesP.  Batches take the streams in turn: CUs / max_batch of them,
+    // at most three and one fewer than there are slots (720p x 32: 71 k frames/s with one stream, 124 k with two
+    // of three slots, 146 k with three of six; four were slower again).  One stream when the batch fills the CUs (a
+    // second one gained nothing there); LANECV_LINES_STREAMS overrides the count.
+    std::vector<hipStream_t> st_lines_more;
+    unsigned lines_turn = 0;
+    // The streaming front kernel's unit height (fixed for the pipeline's largest batch: its change tracking is per unit)
+    // and, for pipelines with an ROI, which units it classifies at all.  The final edge map is the hysteresis result
+    // INSIDE the ROI, and that depends on pixels outside it only through weak pixels that connect the two.  The front
+    // kernel classifies the units (strip x row segment) that come within 15 pixels of the ROI; launch_ring_check proves per
+    // frame that nothing further out can matter (one of the 15 rings around the ROI without leftover weak pixels), and the
+    // rare frame it cannot prove it for is classified again in full.  Not with intermediates (the pre-ROI edge map
+    // must then be complete).  row_split: the first row of the lower region of the unit grid (rows above hold no
+    // needed unit).
+    int front_rows = 0, row_split = 0, roi_first_row = 0;
+    // Levels of the scheme, tightest first: [0] the units within 15 pixels of the ROI, rings around the ROI; [1] all units
+    // from row_split down, "rings" = the rows between row_split and the ROI's first row (the same proof around the band of
+    // rows the ROI spans: for recipes whose weak pixels connect everything near the ROI, as the F1 tracker's low Canny
+    // thresholds do, but not the sky above it).  `level` is what the next batch uses; nlevels = classify in full.  A batch
+    // in which more than a sixteenth of the frames needed the full pass after all moves the pipeline one level out for
+    // the next 256 batches, after which it tries one level in again.  A slot that goes back to a tighter level has the
+    // plane rows of the units that level does not need cleared first (for every frame: `ones`).
+    struct SkipLevel {
+        DevBuf<uint16_t> needed, unneeded;      // units: segment | strip << 8
+        int n_needed = 0, n_unneeded = 0, n_ring_words = 0;
+        DevBuf<uint32_t> ring_words;            // plane words that hold ring pixels
+        DevBuf<uint64_t> ring_code;             // four bit planes: the ring number (1..15) of every pixel, 0 = in no ring
+        long long pixels = 0;                   // pixels per frame of the needed units
+    };
+    SkipLevel levels[2];
+    int nlevels = 0, level = 0, level_hold = 0;
+    DevBuf<int> ones;
+    long long frame_pixels = 0;
+    FrontSplit split(int lvl, int mode, const int *only) const {
+        if (lvl >= nlevels) return FrontSplit{row_split, 0, only, nullptr, nullptr, 0, 0};
+        const SkipLevel &L = levels[lvl];
+        return FrontSplit{row_split, mode, only, L.needed.p, L.unneeded.p, L.n_needed, L.n_unneeded};
+    }
+    bool fuse_vote = true;        // HoughLinesP's kernel also produces the full-vote accumulator (in LDS, before its own)
+    // HoughLinesP with half a CU's LDS per frame, so that two frames -- of two batches, on two streams -- share a CU:
+    // the kernel is one sequential wavefront per frame and leaves most of a CU idle.  For frame sizes whose working
+    // set usually fits (up to about 2.5 megapixels; 1080p road frames take 55 - 60 KiB).
+    // A frame that needs more falls to the slow general kernel; lc_pipe_wait sees it (status word 2) and the next
+    // `ppht_full_for` batches get a whole CU's LDS per frame again, after which the half size is tried anew.
+    bool ppht_two_per_cu = false;
+    int ppht_full_for = 0;
+    int cu_count = 256;
+    int shared_queues = 0;        // streams of this layout that found no hardware queue of their own (lc_pipe_create)
+
+    // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs).  The HoughLinesP
+    // step of a batch is therefore not queued when the batch is submitted but when the NEXT one is, behind that
+    // batch's front-end kernel: started at submit time it would run beside two front kernels in a row.  `deferred` is the slot whose HoughLinesP step is still to be queued (-1: none); waiting for
+    // that slot queues it at once.  defer_after: 0 = never defer, 1 = behind the front end, 2 = behind hysteresis.
+    int deferred = -1;
+    int defer_after = 1;
+    // Batches that leave most CUs free (HoughLinesP is one workgroup per frame) do not get a HoughLinesP launch each:
+    // `group_size` consecutive slots form a group whose launch covers all their frames at once, queued when the
+    // group's last slot has been submitted or one of its slots is waited for.  The buffers that launch indexes by frame
+    // (point lists, counts, bit planes, accumulators, segments) are slices of one allocation per group, a slot's
+    // frames following the previous slot's full capacity; 1 = no grouping.
+    struct Group {
+        DevBuf<uint32_t> nz;
+        DevBuf<int> npoints, fallback;
+        DevBuf<uint64_t> rowplane;
+        DevBuf<int32_t> acc_full, acc_ppht;
+        int32_t *h_res = nullptr;          // pinned: [segcount G*B][rounds G*B][status 8*G][segments G*B*cap*4]
+        int32_t *d_res = nullptr;          // the same block as the GPU addresses it
+        std::vector<int> pending;          // slots with points queued and HoughLinesP not yet, in submission order
+    };
+    int group_size = 1;
+    std::vector<Group> groups;
+    std::vector<Slot> slots;
+};
+
+namespace lanecv {
+
+enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END, EV_ESTART, EV_LSTART, EV_VSTART };
+
+// queues what is still to be queued of the pipeline's batches (deferred HoughLinesP steps, open slot groups)
+void pipe_flush_pending(lc_pipe *pipe);
+
+}  // namespace lanecv

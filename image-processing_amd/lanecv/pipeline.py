@@ -280,6 +280,12 @@ class LanePipeline:
         _abi.check(_abi.lib().lc_pipe_shared_queues(self._h, C.byref(n)))
         return n.value
 
+    def layout(self):
+        """(slots per HoughLinesP launch, HoughLinesP streams, levels of the ROI scheme)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _abi.check(_abi.lib().lc_pipe_layout(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def stage_ms(self, slot, stage):
         ms = C.c_float()
         _abi.check(_abi.lib().lc_pipe_stage_ms(self._h, slot, stage, C.byref(ms)))

@@ -268,6 +268,11 @@ int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_
  * which ones share).  0 = every stage overlaps as designed; otherwise stages that were meant to run side by side
  * were put on one stream. */
 int lc_pipe_shared_queues(lc_pipe *pipe, int *count);
+/* Diagnostics with no counterpart in the reference: how the pipeline laid itself out.  *group_size = consecutive slots
+ * whose HoughLinesP runs as ONE launch (1: a launch per slot; more for batches that leave most CUs free, see
+ * lc_pipe_create), *lines_streams = streams HoughLinesP launches take in turn, *roi_levels = levels of the ROI scheme
+ * (0: every frame is classified in full).  Any pointer may be NULL. */
+int lc_pipe_layout(lc_pipe *pipe, int *group_size, int *lines_streams, int *roi_levels);
 /* Synchronous copy of nframes host frames into the slot's own input buffer, nothing else:
  * a later lc_pipe_submit_device on that pointer then runs with the input resident in HBM. */
 int lc_pipe_upload(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes);

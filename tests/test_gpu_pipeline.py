@@ -414,3 +414,60 @@ def test_roi_skipping_switches_off_and_on_again(oracle, monkeypatch):
             got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
             assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (b, i)
     pipe.close()
+
+
+def test_short_batch_at_a_level_change_clears_every_frame(oracle, monkeypatch):
+    """A slot that comes back to a tighter level of the ROI scheme has the plane rows outside that level's units cleared
+    -- for every frame it can hold, not only for the frames of the batch that happens to come first: here that batch
+    is short (the end of a clip), and a later full batch at the same level must not flood from what an earlier full
+    batch, classified in full, left behind in the frames the short one did not touch.  The last batch is built to
+    show it: a faint vertical edge, weak everywhere (so not an edge at all), exactly under where the earlier frames
+    had a strong one above the rows this level classifies."""
+    monkeypatch.setenv("LANECV_SKIP_OFF_BATCHES", "3")
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h, B = 960, 540, 6
+    rec = Recipe.north_star(w, h)
+    pipe = LanePipeline(w, h, rec, max_batch=B, nslots=2, seg_capacity=512)
+    x = w // 2 + 40
+
+    def column(ytop):
+        g = np.full((h, w), 60, np.int32)
+        g[:ytop, x:] += 120                      # strong above ytop
+        g[ytop:, x:] += 60                       # weak below
+        return np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+
+    first = pipe.row_skip(0)[0]
+    assert first == h // 2 - 15
+    strong_top, strong_to_split, weak_only = column(100), column(first), column(0)
+    road = [synth.synth_road(w, h, seed=47, t=t) for t in range(B)]
+    assert not _oracle_frame(oracle, weak_only, rec, pipe.roi)["masked"].any()
+    plan = [                                     # (slot, frames, pixels classified < whole frame, frames redone)
+        (0, [strong_top] * B, True, B),                      # units near the ROI: all redone -> one level out for 3 batches
+        (0, [strong_top] * B, True, B),                      # rows from above the ROI down: all redone -> in full
+        (0, [strong_to_split] * B, False, B),                # in full: strong bits just above the first row classified
+        (0, [strong_to_split] * B, False, B),
+        (0, [strong_to_split] * B, False, B),
+        (0, road[:2], True, 0),                              # back at the row level with a SHORT batch: the clear
+        (1, [strong_top] * B, True, B),                      # units level on the other slot: redone -> out to the row level
+        (0, [weak_only] * B, True, B),                       # the row level again, full batch, no clear in between: the weak
+                                                             # column crosses every ring row and stays weak -> redone, no edge
+        (0, road, False, B),                                 # (in full: the batch before was redone whole)
+    ]
+    for b, (slot, frames, less, redone) in enumerate(plan):
+        frames = np.stack(frames)
+        pipe.submit(slot, frames)
+        segs = pipe.collect(slot)
+        masked, acc = pipe.read(slot, _abi.BUF_MASKED), pipe.read(slot, _abi.BUF_ACC)
+        _, pixels, got_redone = pipe.roi_skip(slot)
+        assert (pixels < w * h) == less and got_redone == redone, (b, pixels, got_redone)
+        want = {}
+        for i, f in enumerate(frames):
+            key = hash(f.tobytes())
+            r = want.get(key) or _oracle_frame(oracle, f, rec, pipe.roi)
+            want[key] = r
+            assert (masked[i] == r["masked"]).all(), (b, i)
+            assert (acc[i] == r["acc"]).all(), (b, i)
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (b, i)
+    pipe.close()
