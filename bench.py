@@ -68,7 +68,7 @@ def vote_rates(dev_ptr, batch, device):
     from lanecv.pipeline import LanePipeline, Recipe
     rec = Recipe.north_star(W, H)
     rec.segments = False
-    pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=1, device=device)
+    pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=1, device=device, timing=True)
     ms = []
     for _ in range(6):
         pipe.submit_device(0, dev_ptr, batch)
@@ -191,7 +191,7 @@ def main():
     if os.environ.get("LANECV_BENCH_START_AT"):       # diagnostics: several benches on one GPU starting in step
         while time.time() < float(os.environ["LANECV_BENCH_START_AT"]):
             time.sleep(0.0005)
-    pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=args.slots, seg_capacity=SEG_CAP, device=local_rank)
+    pipe = LanePipeline(W, H, rec, max_batch=batch, nslots=args.slots, seg_capacity=SEG_CAP, device=local_rank, timing=True)
 
     # inputs resident in HBM: per clip `nbatches` batches of `batch` frames
     frame_bytes = 3 * W * H

@@ -476,7 +476,7 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
     const int na = wk.hg.numangle, nr = wk.hg.numrho;
     if ((rc = up2d(ctx->tmpA.p, img, w, h, stride, ctx->stream))) return rc;
     if ((rc = points_from_bytes(ctx, nullptr))) return rc;
-    HIP_TRY(hipMemsetAsync(wk.status.p, 0, 4 * sizeof(int), ctx->stream));
+    HIP_TRY(hipMemsetAsync(wk.status.p, 0, 8 * sizeof(int), ctx->stream));
     const int line_length = (int)lrint(min_line_length), line_gap = (int)lrint(max_line_gap);
     const bool fast = launch_ppht_fast(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, threshold, line_length,
                                        line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, RNG_TABLE,

@@ -26,6 +26,23 @@ inline Geo make_geo(int W, int H) {
     Geo g; g.W = W; g.H = H; g.TX = (W + TILE - 1) / TILE; g.TY = (H + TILE - 1) / TILE; return g;
 }
 
+// Which frames of a launch take part in it.  A pipeline slot holds the batches of up to MAX_PARTS callers' submits
+// back to back (part j at frames [j * per_part, (j + 1) * per_part)); a launch covers the slot's frames from 0 up to
+// the last part that takes part, and every kernel leaves the frames outside the set alone -- no reads, no writes:
+// another launch may be working on them.  per_part == 0: every frame of the launch takes part.
+constexpr int MAX_PARTS = 16;
+struct FrameSet {
+    int per_part;
+    int count[MAX_PARTS];       // frames of part j that take part (0: none)
+    __host__ __device__ int part(int f) const { return per_part ? f / per_part : 0; }
+    __host__ __device__ bool has(int f) const {
+        if (!per_part) return true;
+        const int j = f / per_part;
+        return f - j * per_part < count[j];
+    }
+    __host__ __device__ bool first_of_part(int f) const { return per_part ? (f % per_part == 0 && count[f / per_part] > 0) : f == 0; }
+};
+
 // Per-angle constants of HoughLinesProbabilistic, computed on the host exactly
 // as OpenCV's CPU code does (double cos/sin scaled by the float 1/rho, narrowed
 // to float; the walk step uses float division) and uploaded once.
@@ -80,10 +97,10 @@ int front_stream_strips(Geo g);     // 248-column strips per frame row
 int front_stream_rows_per_unit(Geo g, int max_batch, int rows_classified);   // rows_classified: 0 = all of them
 // Pixels the final edge map cannot depend on need not be classified.  With an ROI a pipeline classifies only the units
 // (strip x row segment) that come within RING pixels of it: a launch in mode 1 does those (`needed`, or without a list all
-// units from row_split down); launch_ring_check then decides per frame whether that was enough; a launch in mode 0 with
-// only_frames redoes the frames for which it was not, all units; and once their planes have been consumed a launch in mode
-// 2 (with the same flags) clears the plane rows of the other units (`unneeded`) that the full pass stored, so that the
-// next batch finds them empty again.
+// units from row_split down); launch_hysteresis then decides per frame whether that was enough; a launch in mode 0 with
+// only_frames redoes the frames for which it was not, all units; and before the buffers are next used at a level that
+// skips units a launch in mode 2 clears the plane rows of the other units (`unneeded`) that the full pass stored, so
+// that the next batch finds them empty again.
 struct FrontSplit {
     int row_split;              // > 0: rows above it form a region of units of their own (never needed)
     int mode;                   // 0: all units; 1: the needed units only; 2: clear the plane rows of the unneeded units
@@ -97,7 +114,9 @@ FrontGrid front_stream_grid(Geo g, int rows_per_unit, int row_split);
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                          int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags = nullptr,
-                         bool dec3 = false, const FrontSplit *split = nullptr);
+                         bool dec3 = false, const FrontSplit *split = nullptr, const FrameSet *fs = nullptr,
+                         const uint8_t *const *src_parts = nullptr);
+// fs / src_parts (may be null): the frames that take part, and where each part's frames start (src is ignored then)
 // dec3: src holds frames of 3 W x 3 H pixels; the kernel takes source pixel (3x + 1, 3y + 1) for pixel (x, y), which is
 // what cv2.resize's bilinear reduction by exactly three yields (no gate, no intermediate images in this form)
 void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, hipStream_t st);
@@ -113,46 +132,47 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
                   int low, int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake,
                   uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
                   const GateDev *gate = nullptr, const int *tab = nullptr, uint8_t *gate_gray = nullptr,
-                  uint8_t *rowflags = nullptr, bool dec3 = false, int rows_per_unit = 0, const FrontSplit *split = nullptr);
+                  uint8_t *rowflags = nullptr, bool dec3 = false, int rows_per_unit = 0, const FrontSplit *split = nullptr,
+                  const FrameSet *fs = nullptr, const uint8_t *const *src_parts = nullptr);
 // rows_per_unit (streaming kernel; 0 = derived from nframes): pipelines pass the value of their largest batch, so that
 // the unit grid -- and with it the per-unit change tracking behind rowflags -- does not move with the batch size
 // hysteresis to the fixed point: one workgroup per frame floods the tiles flagged in wake (by the front
 // kernel: those with weak pixels), then repeats over the tiles whose neighbours gained a strong border pixel
 // until a round flags none; rounds[f] receives the rounds frame f needed.  wake holds two arrays of
 // nframes * tiles flags (the second all zero on entry); both are all zero on exit.
-// status (may be null): three words this kernel zeroes; the kernels behind it on the stream raise them with plain stores
-// ([0], [1]: launch_points; [2]: a frame did not fit the LDS the fast HoughLinesP kernel was launched with)
-void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
-                       hipStream_t st, int *status = nullptr, const int *only_frames = nullptr);
+// status (may be null): five words a launch over all frames zeroes; this kernel and the kernels behind it on the stream
+// raise them with plain stores -- [0] a frame holds more edge points than its list keeps (launch_points, HoughLinesP),
+// [1] a vote left the accumulator, [2] a frame did not fit the LDS the fast HoughLinesP kernel was launched with,
+// [3] a frame must be classified again in full (below), [4] a frame is left to the general HoughLinesP kernel
 // only_frames (may be null): device flags, one per frame; frames whose flag is 0 are left alone
-// After hysteresis over the needed units only: does anything outside them matter to frame f?  Ring k = the pixels at
-// Chebyshev distance k from the ROI (k = 1..15; the needed units cover them all).  A chain of candidate pixels from an
-// ROI pixel to a strong pixel further out passes through every ring (the distance changes by at most one per step), and
-// if the ROI pixel is not an edge already, every pixel of the chain inside the rings is a weak pixel that stayed weak.
-// redo[f] = 1 iff such pixels connect ring 1 to ring 15 (8-neighbours, flooded from all of ring 1's), or there are too
-// many of them to tell.
-// ring_words: indices of the plane words that hold ring pixels; code[b]: bit plane b of the ring number (0 = no ring).
-// status (may be null): word 3 is set if any frame was flagged.
-void launch_ring_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, const uint32_t *ring_words,
-                       int nring_words, const uint64_t *code, int *redo, int *status, hipStream_t st, int *rounds = nullptr);
-// rounds (may be null): the per-frame words launch_hysteresis wrote; bit 30 is set in those of the frames flagged
+// ring_code (may be null): after a pass over the units near an ROI only -- does anything outside them matter to frame
+// f?  Ring k = the pixels at Chebyshev distance k from the ROI (k = 1..15; the classified units cover them all).  A
+// chain of candidate pixels from an ROI pixel to a strong pixel further out passes through every ring (the distance
+// changes by at most one per step), and if the ROI pixel is not an edge already, every pixel of the chain inside the
+// rings is a weak pixel that stayed weak.  redo[f] = 1 iff such pixels connect ring 1 to ring 15 (8-neighbours, flooded
+// from all of ring 1's), or there are too many of them to tell; status[3] is raised then and bit 30 of rounds[f] set.
+// ring_words: indices of the plane words that hold ring pixels; ring_code[b]: bit plane b of the ring number (0 = no ring).
+void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
+                       hipStream_t st, int *status = nullptr, const int *only_frames = nullptr,
+                       const uint32_t *ring_words = nullptr, int nring_words = 0, const uint64_t *ring_code = nullptr,
+                       int *redo = nullptr, const FrameSet *fs = nullptr);
+// fs (may be null): the frames that take part; every part then has status words of its own, status + 8 * part
 // roi_bits: one plane shared by all frames, or nullptr
 // prevbits (may be null): the masked bits of the previous call on the same masked_out / rowplane buffers, all
 // zero before the first (like those buffers); with it, and without edges_out, only what changed is written
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits,
                      uint8_t *edges_out, uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st,
-                     uint64_t *prevbits = nullptr);
+                     uint64_t *prevbits = nullptr, const FrameSet *fs = nullptr);   // fs: with prevbits only
 void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t *dst, size_t n, hipStream_t st);
 void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowplane, int *rowcount, hipStream_t st);
 // points + Hough
 // edge points of each frame in scan order from its bit plane and per-row counts (which it clears).  status (may be
-// null) are two words an earlier kernel on the stream zeroed (launch_hysteresis) and this kernel and the Hough kernels
-// behind it raise with plain stores: status[0] = a frame holds more points than the list's capacity (raised here),
-// status[1] = a vote left the accumulator
+// null) are the words an earlier kernel on the stream zeroed (see launch_hysteresis) and this kernel and the Hough
+// kernels behind it raise with plain stores: status[0] = a frame holds more points than the list's capacity (raised here)
 void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, uint32_t *nz, int nz_cap, int *npoints,
-                   int *status, hipStream_t st);
+                   int *status, hipStream_t st, const FrameSet *fs = nullptr);
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
-                 int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st);
+                 int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st, const FrameSet *fs = nullptr);
 // Opt-in to more than 64 KiB of dynamic LDS for a kernel.  The attribute holds for the current device only, so the
 // largest request is remembered per (call site, device); thread-safe.  Returns the HIP error of a failed opt-in.
 struct LdsOptIn {
@@ -176,7 +196,7 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
                       int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes = 0, bool only_flagged = false, int waves = 0,
-                      int status_frames = 0);
+                      int status_frames = 0, const FrameSet *fs = nullptr);
 // status_frames: 0 = one block of status words for the launch; n = frames [k n, (k + 1) n) raise status + 8 k (a launch
 // over the batches of several pipeline slots, each with status words of its own)
 // waves: 8 or 4 wavefronts per frame (0: 4 with ppht_lds_half(), else 8).  Four is for launches that fill every CU twice

@@ -83,13 +83,13 @@ struct Work {
     double rho = 0, theta = 0;
     int seg_cap = 0;
     // pipeline slots keep everything that goes back to the host after a batch in one block, so that one
-    // copy fetches it: [segment counts B][hysteresis rounds B][status, 7 spare][segments B * cap * 4]
+    // copy fetches it: [segment counts B][hysteresis rounds B][8 status words per part][segments B * cap * 4]
     DevBuf<int32_t> resblock;
     size_t res_head = 0;
     int32_t *r_segcount = nullptr, *r_rounds = nullptr, *r_status = nullptr, *r_seg = nullptr;
-    int init_results(int segcap) {
+    int init_results(int segcap, int nparts = 1) {
         int rc;
-        res_head = 2 * (size_t)B + 8;
+        res_head = 2 * (size_t)B + 8 * (size_t)nparts;
         if ((rc = resblock.alloc(res_head + (size_t)B * segcap * 4))) return rc;
         HIP_TRY(hipMemset(resblock.p, 0, sizeof(int32_t) * res_head));
         r_segcount = resblock.p; r_rounds = resblock.p + B; r_status = resblock.p + 2 * (size_t)B; r_seg = resblock.p + res_head;
@@ -135,7 +135,7 @@ struct Work {
         HIP_TRY(hipMemset(rowcount.p, 0, sizeof(int) * (size_t)B * H));
         if ((rc = npoints.alloc(B))) return rc;
         if ((rc = segcount.alloc(B))) return rc;
-        if ((rc = status.alloc(4))) return rc;
+        if ((rc = status.alloc(8))) return rc;
         if ((rc = redo.alloc(B))) return rc;
         HIP_TRY(hipMemset(redo.p, 0, sizeof(int) * (size_t)B));
         if ((rc = fallback.alloc(B))) return rc;

@@ -378,10 +378,9 @@ __device__ __forceinline__ void stF(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the rounds of one frame, run by the HC_THREADS threads of a workgroup; `any` is a word of LDS
-__device__ __forceinline__ void hysteresis_frame(const Geo &g, int f, uint64_t *__restrict__ planeS,
+__device__ __forceinline__ int hysteresis_frame(const Geo &g, int f, uint64_t *__restrict__ planeS,
                                                  const uint64_t *__restrict__ planeW, uint32_t *__restrict__ wakeA,
-                                                 uint32_t *__restrict__ wakeB, int *__restrict__ rounds_out, int &any,
-                                                 const int keep_bits = 0) {
+                                                 uint32_t *__restrict__ wakeB, int &any) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = g.TX * g.TY;
     uint32_t *cur = wakeA + (size_t)f * ntile, *nxt = wakeB + (size_t)f * ntile;   // nxt starts all zero
@@ -414,96 +413,100 @@ __device__ __forceinline__ void hysteresis_frame(const Geo &g, int f, uint64_t *
         uint32_t *tmp = cur; cur = nxt; nxt = tmp;
         rounds++;
     }
-    if (tid == 0 && rounds_out) rounds_out[f] = rounds | keep_bits;
-}
-
-__global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__restrict__ planeS,
-                                                           const uint64_t *__restrict__ planeW,
-                                                           uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
-                                                           int *__restrict__ rounds_out, int *__restrict__ status,
-                                                           const int *__restrict__ only_frames) {
-    __shared__ int any;
-    // (the status words are raised by the kernels behind this one; a launch for a few frames only is such a kernel)
-    if (status && !only_frames && blockIdx.x == 0 && threadIdx.x == 0) status[0] = status[1] = status[2] = status[3] = 0;
-    if (only_frames && only_frames[blockIdx.x] == 0) return;
-    // (a second pass over flagged frames keeps the mark k_ring_check left in the rounds word)
-    hysteresis_frame(g, blockIdx.x, planeS, planeW, wakeA, wakeB, rounds_out, any, only_frames ? 0x40000000 : 0);
+    return rounds;
 }
 
 // ---------------------------------------------------------------------------
-// Was it enough to classify the units near the ROI?  One wavefront per frame (see launch_ring_check in common.h).
-// A pixel outside the classified units can only matter through a chain of weak pixels that stayed weak, leading from
-// the ROI outwards through every ring.  The wavefront lists the leftover weak pixels of the rings (there are few),
-// takes those of ring 1 as reached -- as if every one of them touched such a pixel of the ROI -- and floods from
-// them through 8-neighbours in the list; only if the flood arrives in ring 15 (or the list overflows) is the frame
-// classified again in full.
+// Was it enough to classify the units near the ROI?  (See launch_hysteresis in common.h.)  The frame's workgroup asks
+// once its hysteresis has settled.  A pixel outside the classified units can only matter through a chain of weak
+// pixels that stayed weak, leading from the ROI outwards through every ring.  The workgroup lists the leftover weak
+// pixels of the rings (there are few), takes those of ring 1 as reached -- as if every one of them touched such a pixel
+// of the ROI -- and floods from them through 8-neighbours in the list (a thread per listed pixel); only if the flood
+// arrives in ring 15, or does not settle, or the list overflows, is the frame classified again in full.
 // ---------------------------------------------------------------------------
 constexpr int RING_LIST = 256, RING_ROUNDS = 48;   // beyond either the frame is classified in full rather than looked at longer
-__global__ __launch_bounds__(64) void k_ring_check(Geo g, const uint64_t *__restrict__ planeS, const uint64_t *__restrict__ planeW,
-                                                   const uint32_t *__restrict__ ring_words, int nring_words,
-                                                   const uint64_t *__restrict__ code, int *__restrict__ redo,
-                                                   int *__restrict__ status, int *__restrict__ rounds) {
-    __shared__ uint32_t px[RING_LIST];        // x | y << 13 | ring << 26 | reached << 31
-    __shared__ int count;
-    const int f = blockIdx.x, lane = threadIdx.x;
+struct RingArgs {
+    const uint32_t *ring_words;     // indices of the plane words that hold ring pixels
+    int nring_words;
+    const uint64_t *code;           // four bit planes: the ring number (1..15) of every pixel, 0 = in no ring
+    int *redo;                      // per frame: 1 = classify again in full
+};
+static_assert(RING_LIST <= HC_THREADS, "one thread per listed pixel");
+
+// px: RING_LIST words of LDS, count: one; returns (to every thread) whether frame f must be classified again
+__device__ __forceinline__ bool ring_check_frame(const Geo &g, int f, const uint64_t *__restrict__ planeS,
+                                                 const uint64_t *__restrict__ planeW, const RingArgs &ra, uint32_t *px, int &count) {
+    const int tid = threadIdx.x;
     const size_t words = g.plane_words();
-    if (lane == 0) count = 0;
+    if (tid == 0) count = 0;
     __syncthreads();
-    bool overflow = false;
-    for (int i0 = 0; i0 < nring_words; i0 += 64) {
-        const int i = i0 + lane;
-        uint64_t left = 0;
-        uint32_t w = 0;
-        if (i < nring_words) {
-            w = ring_words[i];
-            left = planeW[(size_t)f * words + w] & ~planeS[(size_t)f * words + w];
-            if (left) left &= code[w] | code[words + w] | code[2 * words + w] | code[3 * words + w];   // ring pixels only
-        }
-        if (__ballot(left != 0) == 0) continue;
-        if (left) {
-            const uint64_t c0 = code[w], c1 = code[words + w], c2 = code[2 * words + w], c3 = code[3 * words + w];
-            const int n = __popcll(left);
-            const int at = atomicAdd(&count, n);
-            const uint32_t y = w / g.TX, xb = (w % g.TX) * 64;
-            int k = 0;
-            for (uint64_t m = left; m; m &= m - 1, k++) {
-                const int b = __builtin_ctzll(m);
-                const uint32_t ring = (uint32_t)((c0 >> b) & 1) | (uint32_t)((c1 >> b) & 1) << 1 | (uint32_t)((c2 >> b) & 1) << 2 |
-                                      (uint32_t)((c3 >> b) & 1) << 3;
-                if (at + k < RING_LIST) px[at + k] = (xb + b) | (y << 13) | (ring << 26) | ((ring == 1 ? 1u : 0u) << 31);
-            }
+    for (int i = tid; i < ra.nring_words; i += HC_THREADS) {
+        const uint32_t w = ra.ring_words[i];
+        uint64_t left = planeW[(size_t)f * words + w];
+        if (left) left &= ~ldS(planeS + (size_t)f * words + w);
+        if (!left) continue;
+        const uint64_t c0 = ra.code[w], c1 = ra.code[words + w], c2 = ra.code[2 * words + w], c3 = ra.code[3 * words + w];
+        left &= c0 | c1 | c2 | c3;                                       // ring pixels only
+        if (!left) continue;
+        const int at = atomicAdd(&count, __popcll(left));
+        const uint32_t y = w / g.TX, xb = (w % g.TX) * 64;
+        int k = 0;
+        for (uint64_t m = left; m; m &= m - 1, k++) {
+            const int b = __builtin_ctzll(m);
+            const uint32_t ring = (uint32_t)((c0 >> b) & 1) | (uint32_t)((c1 >> b) & 1) << 1 | (uint32_t)((c2 >> b) & 1) << 2 |
+                                  (uint32_t)((c3 >> b) & 1) << 3;
+            // x | y << 13 | ring << 26 | reached << 31
+            if (at + k < RING_LIST) px[at + k] = (xb + b) | (y << 13) | (ring << 26) | ((ring == 1 ? 1u : 0u) << 31);
         }
     }
     __syncthreads();
     const int n = count;
-    overflow = n > RING_LIST;
-    bool arrived = false;
-    if (!overflow) {
-        bool settled = false;
-        for (int round = 0; round < RING_ROUNDS && !settled; round++) {
-            bool changed = false;
-            for (int i = lane; i < n; i += 64) {
-                const uint32_t p = px[i];
-                if (p >> 31) continue;
-                const int x = p & 0x1FFF, y = (p >> 13) & 0x1FFF;
-                bool hit = false;
-                for (int j = 0; j < n && !hit; j++) {
-                    const uint32_t q = px[j];
-                    hit = (q >> 31) && abs((int)(q & 0x1FFF) - x) <= 1 && abs((int)((q >> 13) & 0x1FFF) - y) <= 1;
-                }
-                if (hit) { px[i] = p | 0x80000000u; changed = true; }
+    if (n == 0) return false;
+    if (n > RING_LIST) return true;
+    const bool mine = tid < n;
+    const uint32_t p0 = mine ? px[tid] : 0u;
+    const int x = p0 & 0x1FFF, y = (p0 >> 13) & 0x1FFF;
+    bool reached = (p0 >> 31) != 0, settled = false;
+    for (int round = 0; round < RING_ROUNDS && !settled; round++) {
+        bool changed = false;
+        if (mine && !reached) {
+            for (int j = 0; j < n && !changed; j++) {
+                const uint32_t q = px[j];        // (another thread may be setting its bit 31 right now: sooner or later is the same)
+                changed = (q >> 31) && abs((int)(q & 0x1FFF) - x) <= 1 && abs((int)((q >> 13) & 0x1FFF) - y) <= 1;
             }
-            __syncthreads();
-            settled = __ballot(changed) == 0;
+            if (changed) { reached = true; px[tid] = p0 | 0x80000000u; }
         }
-        arrived = !settled;                            // still spreading after RING_ROUNDS: do not look longer
-        for (int i = lane; i < n; i += 64) arrived |= (px[i] >> 31) && ((px[i] >> 26) & 15) == 15;
+        settled = __syncthreads_or(changed ? 1 : 0) == 0;
     }
-    const bool bad = overflow || __ballot(arrived) != 0;
-    if (lane == 0) {
-        redo[f] = bad ? 1 : 0;
+    // still spreading after RING_ROUNDS: do not look longer
+    return __syncthreads_or((!settled || (mine && reached && ((p0 >> 26) & 15) == 15)) ? 1 : 0) != 0;
+}
+
+// status (may be null): the words the kernels behind this one on the stream raise with plain stores; a launch over
+// all frames zeroes them first (see launch_hysteresis in common.h for their meaning)
+__global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__restrict__ planeS,
+                                                           const uint64_t *__restrict__ planeW,
+                                                           uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
+                                                           int *__restrict__ rounds_out, int *__restrict__ status,
+                                                           const int *__restrict__ only_frames, RingArgs ra, FrameSet fs) {
+    __shared__ int any, count;
+    __shared__ uint32_t px[RING_LIST];
+    const int f = blockIdx.x;
+    if (!fs.has(f)) return;
+    if (status) status += 8 * fs.part(f);            // every part has status words of its own
+    if (status && !only_frames && fs.first_of_part(f) && threadIdx.x < 5) status[threadIdx.x] = 0;
+    if (only_frames && only_frames[f] == 0) return;
+    const int rounds = hysteresis_frame(g, f, planeS, planeW, wakeA, wakeB, any);
+    bool bad = false;
+    if (ra.redo) {
+        __syncthreads();
+        bad = ring_check_frame(g, f, planeS, planeW, ra, px, count);
+    }
+    if (threadIdx.x == 0) {
+        if (ra.redo) ra.redo[f] = bad ? 1 : 0;
         if (bad && status) status[3] = 1;        // (plain stores: the words may live in host memory)
-        if (bad && rounds) rounds[f] |= 0x40000000;   // the host counts the frames redone from this bit of the rounds word
+        // bit 30 of the rounds word: the frame is, or (second pass over flagged frames) was, flagged
+        if (rounds_out) rounds_out[f] = rounds | ((bad || only_frames) ? 0x40000000 : 0);
     }
 }
 
@@ -603,11 +606,12 @@ __device__ __forceinline__ void finalize_word(const Geo &g, size_t f, size_t wf,
 __global__ __launch_bounds__(256) void k_finalize_sparse(Geo g, size_t nwords, const uint64_t *__restrict__ planeS,
                                                          const uint64_t *__restrict__ roi_bits, uint64_t *__restrict__ prevbits,
                                                          uint8_t *__restrict__ masked_out, uint64_t *__restrict__ rowplane,
-                                                         int *__restrict__ rowcount) {
+                                                         int *__restrict__ rowcount, FrameSet fs) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nwords) return;
     const size_t words_per_frame = (size_t)g.TX * g.H;
     const size_t f = i / words_per_frame, wf = i % words_per_frame;   // wf = y * TX + tx
+    if (!fs.has((int)f)) return;
     uint64_t M = planeS[i];
     if (roi_bits) M &= roi_bits[wf];
     const uint64_t P = prevbits[i];
@@ -670,13 +674,15 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes, int low,
                   int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                   hipStream_t st, const GateDev *gate, const int *tab, uint8_t *gate_gray, uint8_t *rowflags, bool dec3,
-                  int rows_per_unit, const FrontSplit *split) {
+                  int rows_per_unit, const FrontSplit *split, const FrameSet *fs, const uint8_t *const *src_parts) {
     static const char *force_tiled = getenv("LANECV_FRONT_TILED");       // diagnostics: use the tiled kernel everywhere
     if (in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1')) {
         launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, wake, gray_out, blur_out,
-                            rows_per_unit, gate, tab, st, rowflags, dec3, split);
+                            rows_per_unit, gate, tab, st, rowflags, dec3, split, fs, src_parts);
         return;
     }
+    // (the tiled kernel knows no frame sets: its callers launch it over one part's frames, all of them)
+    if (fs && src_parts) src = src_parts[0];
     if (gate && in_kind == 1) {   // gated gray first, then the tiled kernel on that gray image
         const size_t npix = (size_t)g.W * g.H * nframes;
         launch_gate_gray(src, npix, code, tab, *gate, gate_gray, st);
@@ -692,24 +698,22 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 }
 
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
-                       hipStream_t st, int *status, const int *only_frames) {
+                       hipStream_t st, int *status, const int *only_frames, const uint32_t *ring_words, int nring_words,
+                       const uint64_t *ring_code, int *redo, const FrameSet *fs) {
     // wake holds two flag arrays of nframes * tiles words each.  The second is all zero on entry and both are on
     // exit (zeroed when allocated): the kernel clears every flag it consumes and stops when a round sets none.
     const int nt = g.TX * g.TY * nframes;
-    hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds, status, only_frames);
-}
-
-void launch_ring_check(Geo g, int nframes, const uint64_t *planeS, const uint64_t *planeW, const uint32_t *ring_words,
-                       int nring_words, const uint64_t *code, int *redo, int *status, hipStream_t st, int *rounds) {
-    hipLaunchKernelGGL(k_ring_check, dim3(nframes), dim3(64), 0, st, g, planeS, planeW, ring_words, nring_words, code, redo, status, rounds);
+    const RingArgs ra{ring_words, nring_words, ring_code, ring_code ? redo : nullptr};
+    hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds, status, only_frames, ra,
+                       fs ? *fs : FrameSet{});
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,
-                     uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st, uint64_t *prevbits) {
+                     uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st, uint64_t *prevbits, const FrameSet *fs) {
     if (prevbits && !edges_out && masked_out) {
         const size_t nwords = (size_t)g.TX * g.H * nframes;
         hipLaunchKernelGGL(k_finalize_sparse, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, g, nwords, planeS, roi_bits,
-                           prevbits, masked_out, rowplane, rowcount);
+                           prevbits, masked_out, rowplane, rowcount, fs ? *fs : FrameSet{});
         return;
     }
     int nt = g.TX * g.TY * nframes;

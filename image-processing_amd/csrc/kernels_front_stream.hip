@@ -135,7 +135,8 @@ __device__ __forceinline__ int reflect101s(int p, int len) {
 }
 
 struct FrontArgs {
-    const uint8_t *src;
+    const uint8_t *src[MAX_PARTS];   // where the frames of each part start (one part without a frame set)
+    FrameSet fs;
     Geo g;
     uint32_t k_lo, k_hi;     // low / high bytes of twice the three 15-bit gray weights, in memory channel order
     int low, high;
@@ -202,7 +203,8 @@ __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, cons
     constexpr int RS = DEC3 ? 3 : 1;               // source pixels per pixel, each way
     constexpr int NL = DEC3 ? 6 : 3;               // dwords a lane keeps of a source row
     const size_t frame_bytes = (size_t)3 * (RS * W) * (RS * H);
-    const uint8_t *fsrc = a.src + (size_t)f * frame_bytes;
+    const int part = a.fs.part(f);
+    const uint8_t *fsrc = a.src[part] + (size_t)(f - part * a.fs.per_part) * frame_bytes;
     // lanes outside the image load a valid pixel group instead of nothing: what they hold never reaches
     // an output (border lanes are rewritten below, magnitudes outside the image are forced to zero)
     const uint32_t lane_off = (uint32_t)(3 * RS) * (uint32_t)min(max(px, 0), W - 4);
@@ -527,6 +529,7 @@ __device__ __forceinline__ void front_stream_body(const FrontArgs &a) {
     const bool hb = STRIP * s - 4 < 0 || ((a.g.W - (STRIP * s - 4)) >> 2) <= 63;
     const bool fe = y0 == 0 || y1 + DB + 1 >= H;        // rows y0 - DB - 2 .. y1 + DB + 1 are loaded
     auto unit = [&](const int f) {
+        if (!a.fs.has(f)) return;
         if (hb) {
             if (fe) front_unit<BLUR, GATE, INTER, true, true, DEC3>(a, f, s, y0, y1);
             else front_unit<BLUR, GATE, INTER, true, false, DEC3>(a, f, s, y0, y1);
@@ -572,7 +575,8 @@ __global__ __launch_bounds__(256) void k_front_clear(FrontArgs a) {
         const int fl = base + REDO_GROUPS * (int)(threadIdx.x & 63);
         uint64_t todo = __ballot(fl < a.nframes && a.only_frames[fl] != 0);
         while (todo) {
-            clear_unit<BLUR>(a, base + REDO_GROUPS * __builtin_ctzll(todo), s, y0, y1);
+            const int f = base + REDO_GROUPS * __builtin_ctzll(todo);
+            if (a.fs.has(f)) clear_unit<BLUR>(a, f, s, y0, y1);
             todo &= todo - 1;
         }
     }
@@ -618,13 +622,15 @@ FrontGrid front_stream_grid(Geo g, int rows_per_unit, int row_split) {
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                          int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags, bool dec3,
-                         const FrontSplit *split) {
+                         const FrontSplit *split, const FrameSet *fs, const uint8_t *const *src_parts) {
     FrontArgs a;
+    a.fs = fs ? *fs : FrameSet{};
+    for (int j = 0; j < MAX_PARTS; j++) a.src[j] = (fs && src_parts) ? src_parts[j] : src;
     a.wake = wake;
     a.rowflags = rowflags;
     a.gate_tab = tab;
     if (gate) a.gate = *gate; else a.gate = GateDev{};
-    a.src = src; a.g = g; a.low = low; a.high = high;
+    a.g = g; a.low = low; a.high = high;
     a.planeS = planeS; a.planeW = planeW; a.gray_out = gray_out; a.blur_out = blur_out;
     // twice the 15-bit weights, so that the gray value lands on a byte boundary of the sum
     const uint32_t k0 = 2 * (code == 6 ? 3735 : 9798), k1 = 2 * 19235, k2 = 2 * (code == 6 ? 9798 : 3735);

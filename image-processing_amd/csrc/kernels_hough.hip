@@ -31,9 +31,11 @@ constexpr int POINTS_WAVES = LC_POINTS_WAVES;
 
 __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint64_t *__restrict__ rowplane,
                                                                int *__restrict__ rowcount, uint32_t *__restrict__ nz, int nz_cap,
-                                                               int *__restrict__ npoints, int *__restrict__ status) {
+                                                               int *__restrict__ npoints, int *__restrict__ status, FrameSet fs) {
     __shared__ int tot[POINTS_WAVES];
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (!fs.has(f)) return;
+    if (status) status += 8 * fs.part(f);
     const int H = g.H, TX = g.TX;
     const int rpw = (H + POINTS_WAVES - 1) / POINTS_WAVES;
     const int r0 = min(H, wv * rpw), r1 = min(H, r0 + rpw);
@@ -175,9 +177,10 @@ __device__ __forceinline__ void vote_frame(int *lacc, int f, int a_first, int a_
 
 __global__ __launch_bounds__(256) void k_vote(const uint32_t *__restrict__ nz, int nz_cap, const int *__restrict__ npoints,
                                                const AngleEntry *__restrict__ tab, int numangle, int numrho, int apg,
-                                               int32_t *__restrict__ acc, const int *__restrict__ flags) {
+                                               int32_t *__restrict__ acc, const int *__restrict__ flags, FrameSet fs) {
     extern __shared__ int lacc[];
     const int f = blockIdx.y;
+    if (!fs.has(f)) return;
     if (flags && !(flags[f] & 2)) return;   // HoughLinesP already produced this frame's accumulator
     // a block takes the angle groups blockIdx.x, blockIdx.x + gridDim.x, ...
     vote_frame(lacc, f, blockIdx.x, gridDim.x, nz, nz_cap, npoints, tab, numangle, numrho, apg, acc);
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
                                                    int32_t *__restrict__ seg_all, int seg_cap, int *__restrict__ seg_count,
                                                    int *__restrict__ status, int *__restrict__ fallback, int lds_points,
                                                    const uint32_t *__restrict__ rng_out, int lds_bytes,
-                                                   int32_t *__restrict__ acc_full, int only_flagged, int status_frames) {
+                                                   int32_t *__restrict__ acc_full, int only_flagged, int status_frames, FrameSet fs) {
     constexpr int PPHT_THREADS = 64 * PPHT_WAVES;
     extern __shared__ __align__(16) uint32_t lds32[];
     __shared__ int progress;
@@ -776,7 +779,9 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     __shared__ int a_rmin[64];
     __shared__ AngleEntry s_tab[64];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // one launch may cover the batches of several pipeline slots: every status_frames frames have status words of their own
+    if (!fs.has(f)) return;
+    // one launch may cover the batches of several callers (parts of a pipeline slot): every status_frames frames have
+    // status words of their own
     if (status_frames) status += 8 * (f / status_frames);
 #ifdef LC_STAMPS
     if (f == 0 && lane == 0) g_simd[wave] = __builtin_amdgcn_s_getreg(2308);
@@ -789,12 +794,17 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         if (tid == 0) { seg_count[f] = 0; fallback[f] = 2; status[0] = 1; }
         return;
     }
-    if (n == 0) {
-        if (tid == 0) { seg_count[f] = 0; fallback[f] = 2; }
+    if (n == 0) {                            // no edge points: no segments, an accumulator of zeros
+        if (acc_full) {
+            int32_t *out = acc_full + (size_t)f * numangle * numrho;
+            for (int i = tid; i < numangle * numrho; i += PPHT_THREADS) out[i] = 0;
+        }
+        if (tid == 0) { seg_count[f] = 0; fallback[f] = 0; }
         return;
     }
+    // status[4]: some frame is left to the general kernel -- which the caller may then launch only when this is raised
     if (n > lds_points || n >= LDS_BIAS) {   // biased 16-bit bins hold counts in (-LDS_BIAS, LDS_BIAS)
-        if (tid == 0) fallback[f] = 3;
+        if (tid == 0) { fallback[f] = 3; status[4] = 1; }
         return;
     }
     Ppht c;
@@ -815,7 +825,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     const size_t rt_off = ((size_t)n + 3) & ~(size_t)3;          // 16-byte aligned
     uint32_t *rowtab = lds32 + rt_off;
     if ((rt_off + 4 * (size_t)nrows) * 4 > (size_t)lds_bytes) {  // (the row table alone does not fit)
-        if (tid == 0) { fallback[f] = 3; status[2] = 1; }
+        if (tid == 0) { fallback[f] = 3; status[2] = 1; status[4] = 1; }
         return;
     }
     if (tid == 0) {
@@ -909,7 +919,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     // holding two frames.
     const size_t mask_off = (acc_off + acc_words + 1) & ~(size_t)1;
     if ((mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes) {
-        if (tid == 0) { fallback[f] = 3; status[2] = 1; }   // does not fit: the general kernel (and its vote) take the frame
+        if (tid == 0) { fallback[f] = 3; status[2] = 1; status[4] = 1; }   // does not fit: the general kernel (and its vote) take the frame
         return;
     }
     if (tid == 0) fallback[f] = 0;
@@ -1207,8 +1217,9 @@ hipError_t LdsOptIn::ensure(const void *kernel, size_t bytes) {
 }
 
 void launch_points(Geo g, int nframes, const uint64_t *rowplane, int *rowcount, uint32_t *nz, int nz_cap, int *npoints,
-                   int *status, hipStream_t st) {
-    hipLaunchKernelGGL(k_points, dim3(nframes), dim3(64 * POINTS_WAVES), 0, st, g, rowplane, rowcount, nz, nz_cap, npoints, status);
+                   int *status, hipStream_t st, const FrameSet *fs) {
+    hipLaunchKernelGGL(k_points, dim3(nframes), dim3(64 * POINTS_WAVES), 0, st, g, rowplane, rowcount, nz, nz_cap, npoints, status,
+                       fs ? *fs : FrameSet{});
 }
 
 // angle rows per workgroup of the vote: what fits 6 KiB of LDS, at least one.  Small on purpose: the kernel then
@@ -1222,7 +1233,7 @@ static int vote_apg(int numangle, int numrho, int &groups, int budget = 6 * 1024
 }
 
 void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *npoints, const AngleEntry *tab,
-                 int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st) {
+                 int numangle, int numrho, int32_t *acc, const int *flags, hipStream_t st, const FrameSet *fs) {
     (void)g;
     int groups;
     // on its own (no flags) the kernel does not share CUs with HoughLinesP: 16 KiB of rows per workgroup (eight
@@ -1236,7 +1247,7 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
     // the flagged launch (often no frame has work) is at most 8 blocks per frame: it must not queue thousands of
     // blocks that only look at a flag behind the waves of the kernels it shares the GPU with
     hipLaunchKernelGGL(k_vote, dim3(flags ? std::min(groups, 8) : groups, nframes), dim3(256), lds, st, nz, nz_cap, npoints, tab, numangle,
-                       numrho, apg, acc, flags);
+                       numrho, apg, acc, flags, fs ? *fs : FrameSet{});
 }
 
 int ppht_lds_half() { return PPHT_LDS_HALF; }
@@ -1248,7 +1259,7 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
                       int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged, int waves,
-                      int status_frames) {
+                      int status_frames, const FrameSet *fs) {
     // points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not fit lds_bytes (the
     // kernel decides, per frame) is flagged.
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
@@ -1261,12 +1272,12 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
         if (optin4.ensure(reinterpret_cast<const void *>(k_ppht_fast<4>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
         hipLaunchKernelGGL(k_ppht_fast<4>, dim3(nframes), dim3(256), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames);
+                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
     } else {
         if (optin8.ensure(reinterpret_cast<const void *>(k_ppht_fast<8>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
         hipLaunchKernelGGL(k_ppht_fast<8>, dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames);
+                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
     }
     return true;
 }

@@ -8,23 +8,36 @@ using lanecv::GateDev;
 using lanecv::FrontSplit;
 
 // ---------------------------------------------------------------------------
+// What a caller submits into and waits for.  A slot owns no buffers: it is a place in a bank.
 struct Slot {
-    Work w;
-    hipEvent_t ev[12] = {};
+    int bank = 0, pos = 0;            // its bank and its place there: frames [pos * max_batch, (pos + 1) * max_batch) of the bank's buffers
     int nframes = 0;
-    const uint8_t *input = nullptr;   // device pointer of the frames of the batch in flight
-    size_t input_bytes = 0;
-    bool busy = false, timed = false;
-    int level = 0;                // ROI-scheme level of the batch in flight (or last); the pipeline's nlevels = classified in full
-    int planes_level = 0;         // loosest level a batch of this slot ran at since its planes were last cleared down
-    int group = 0, gpos = 0;      // group of slots whose HoughLinesP runs as one launch, and the slot's place in it
-    bool lines_pending = false;   // the batch's points are queued, its HoughLinesP launch is not yet
-    // pinned host mirror of the slot's result block
-    int32_t *h_res = nullptr;
-    bool zero_copy = false;       // the kernels write the result block straight into h_res (mapped pinned memory)
-    int end_ev = 0;               // the event that marks the batch complete (index into ev)
+    const uint8_t *input = nullptr;   // device pointer of the submitted frames (inside the bank's own input buffer for host submits)
+    bool from_host = false;
+    bool busy = false;                // submitted and not yet waited for
+    bool pending = false;             // submitted, but the bank's kernels for it are not queued yet
+    bool timed = false;               // the launch that covers it recorded the stage events
+    bool fast_lines = false;          // its HoughLinesP ran in the LDS-resident kernel, which may leave frames to the general one
+    int level = 0;                    // ROI-scheme level of the launch that covers it; the pipeline's nlevels = classified in full
+    hipEvent_t done = nullptr;        // fires when the launch that covers the slot has finished
+    // its part of the bank's pinned result block
     int *h_rounds = nullptr, *h_status = nullptr, *h_segcount = nullptr;
     int32_t *h_seg = nullptr;
+};
+
+// A set of buffers for `parts` slots back to back, and the events of its launches.  Batches that fill the GPU get a
+// bank each (parts = 1).  Batches that leave most CUs free -- every kernel behind the front kernel is one workgroup
+// per frame, and what the host pays per launch does not shrink with the batch -- share one: the kernels are queued
+// when the bank's last slot has been submitted (or one of its slots is waited for), ONE launch each over the frames
+// of all the slots submitted since the last time (a FrameSet says which; the kernels leave every other frame alone,
+// an earlier launch over other slots of the bank may still be running).
+struct Bank {
+    Work w;
+    int parts = 1;
+    hipEvent_t ev[12] = {};           // of the bank's latest launch (stage times, and the waits between its streams)
+    int planes_level = 0;             // loosest level a launch of this bank ran at since its planes were last cleared down
+    int32_t *h_res = nullptr;         // pinned host mirror of the result block: [segcount][rounds][status 8 * parts][segments]
+    bool zero_copy = false;           // the kernels write the result block straight into h_res (mapped pinned memory)
 };
 
 struct lc_pipe {
@@ -70,7 +83,7 @@ struct lc_pipe {
     // The streaming front kernel's unit height (fixed for the pipeline's largest batch: its change tracking is per unit)
     // and, for pipelines with an ROI, which units it classifies at all.  The final edge map is the hysteresis result
     // INSIDE the ROI, and that depends on pixels outside it only through weak pixels that connect the two.  The front
-    // kernel classifies the units (strip x row segment) that come within 15 pixels of the ROI; launch_ring_check proves per
+    // kernel classifies the units (strip x row segment) that come within 15 pixels of the ROI; the hysteresis kernel proves per
     // frame that nothing further out can matter (one of the 15 rings around the ROI without leftover weak pixels), and the
     // rare frame it cannot prove it for is classified again in full.  Not with intermediates (the pre-ROI edge map
     // must then be complete).  row_split: the first row of the lower region of the unit grid (rows above hold no
@@ -109,29 +122,12 @@ struct lc_pipe {
     int ppht_full_for = 0;
     int cu_count = 256;
     int shared_queues = 0;        // streams of this layout that found no hardware queue of their own (lc_pipe_create)
+    hipEvent_t ev_base = nullptr; // recorded when stage times were first switched on
+    bool timing = false;          // record the events lc_pipe_stage_ms reads (lc_pipe_set_timing); a dozen more packets per batch
 
-    // HoughLinesP and the front-end kernel slow each other down most (both want the vector ALUs).  The HoughLinesP
-    // step of a batch is therefore not queued when the batch is submitted but when the NEXT one is, behind that
-    // batch's front-end kernel: started at submit time it would run beside two front kernels in a row.  `deferred` is the slot whose HoughLinesP step is still to be queued (-1: none); waiting for
-    // that slot queues it at once.  defer_after: 0 = never defer, 1 = behind the front end, 2 = behind hysteresis.
-    int deferred = -1;
-    int defer_after = 1;
-    // Batches that leave most CUs free (HoughLinesP is one workgroup per frame) do not get a HoughLinesP launch each:
-    // `group_size` consecutive slots form a group whose launch covers all their frames at once, queued when the
-    // group's last slot has been submitted or one of its slots is waited for.  The buffers that launch indexes by frame
-    // (point lists, counts, bit planes, accumulators, segments) are slices of one allocation per group, a slot's
-    // frames following the previous slot's full capacity; 1 = no grouping.
-    struct Group {
-        DevBuf<uint32_t> nz;
-        DevBuf<int> npoints, fallback;
-        DevBuf<uint64_t> rowplane;
-        DevBuf<int32_t> acc_full, acc_ppht;
-        int32_t *h_res = nullptr;          // pinned: [segcount G*B][rounds G*B][status 8*G][segments G*B*cap*4]
-        int32_t *d_res = nullptr;          // the same block as the GPU addresses it
-        std::vector<int> pending;          // slots with points queued and HoughLinesP not yet, in submission order
-    };
-    int group_size = 1;
-    std::vector<Group> groups;
+    // slots per bank (see Bank), frames a bank holds, and the banks
+    int parts = 1, bank_frames = 0;
+    std::vector<Bank> banks;
     std::vector<Slot> slots;
 };
 
@@ -139,7 +135,7 @@ namespace lanecv {
 
 enum { EV_START = 0, EV_UPLOADED, EV_FRONT, EV_HYST, EV_EDGE, EV_POINTS, EV_VOTE, EV_LINES, EV_END, EV_ESTART, EV_LSTART, EV_VSTART };
 
-// queues what is still to be queued of the pipeline's batches (deferred HoughLinesP steps, open slot groups)
+// queues what is still to be queued of the pipeline's batches (slots submitted into banks that are not full yet)
 void pipe_flush_pending(lc_pipe *pipe);
 
 }  // namespace lanecv

@@ -1,10 +1,30 @@
 // The batched pipeline's set-up: the ROI plane and the levels of the ROI scheme, the streams (each with a hardware
-// queue of its own, found by experiment), the slots' buffers and the slot groups; and its tear-down.
+// queue of its own, found by experiment), the banks of buffers and the slots' places in them; and its tear-down.
 #include "pipe.h"
 
 using namespace lanecv;
 
 namespace {
+
+// How many slots share a bank of buffers (see Bank): batches that leave most CUs free are queued `parts` at a time.
+// For what the kernels' frame sets cover: the streaming front kernel on frames as submitted (or its fused reduction by
+// three), no intermediates.  LANECV_NO_GROUPS=1 / LANECV_GROUP_SIZE=n: diagnostics.
+void setup_layout(lc_pipe *pp) {
+    const lc_pipe_params &p = pp->p;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, pp->ctx->device) == hipSuccess && prop.multiProcessorCount > 0) pp->cu_count = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    const bool can = !getenv("LANECV_NO_GROUPS") && !p.keep_intermediates && front_stream_supported(pp->g) && !getenv("LANECV_FRONT_TILED") &&
+                     (!pp->resizes || pp->fused_dec3()) && !(getenv("LANECV_RESULT_COPY") && getenv("LANECV_RESULT_COPY")[0] == '1');
+    int parts = 1;
+    if (can && 2 * p.max_batch <= pp->cu_count && p.nslots >= 4) parts = std::min(p.nslots / 2, pp->cu_count / p.max_batch);
+    if (const char *gs = getenv("LANECV_GROUP_SIZE")) {
+        const int v = atoi(gs);
+        if (can && v >= 1 && v <= p.nslots) parts = v;
+    }
+    pp->parts = std::max(1, std::min(parts, (int)MAX_PARTS));
+    pp->bank_frames = pp->parts * p.max_batch;
+}
 
 // cv2.resize in front (tables as OpenCV builds them) and the colour gate's tables
 int setup_front_tables(lc_pipe *pp) {
@@ -85,7 +105,7 @@ int setup_skip_levels(lc_pipe *pp, const std::vector<uint64_t> &bits) {
             rows_forced = atoi(re);
             if (rows_forced < 8 || rows_forced > MAX_DIM) return fail(LC_EINVAL, "LANECV_FRONT_ROWS=%s: expected 8 .. %d rows", re, MAX_DIM);
         }
-        auto unit_rows = [&](int rows_classified) { return rows_forced ? rows_forced : front_stream_rows_per_unit(g, p.max_batch, rows_classified); };
+        auto unit_rows = [&](int rows_classified) { return rows_forced ? rows_forced : front_stream_rows_per_unit(g, pp->bank_frames, rows_classified); };
         // (the per-frame proof packs pixel coordinates into 13 bits each)
         if (pp->has_roi && !p.keep_intermediates && front_stream_supported(g) && !getenv("LANECV_FRONT_TILED") && !ns && g.W <= 8191 &&
             g.H <= 8191) {
@@ -191,7 +211,7 @@ int setup_skip_levels(lc_pipe *pp, const std::vector<uint64_t> &bits) {
                     }
                 }
                 if (pp->nlevels > 0) {
-                    std::vector<int> one(p.max_batch, 1);
+                    std::vector<int> one(pp->bank_frames, 1);
                     if ((rc = pp->ones.alloc(one.size()))) return rc;
                     if (hipMemcpy(pp->ones.p, one.data(), one.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
                         return fail(LC_EHIP, "flag upload failed");
@@ -209,7 +229,6 @@ int setup_skip_levels(lc_pipe *pp, const std::vector<uint64_t> &bits) {
 
 int setup_streams(lc_pipe *pp) {
     const lc_pipe_params &p = pp->p;
-    lc_ctx *ctx = pp->ctx;
     {
         // All streams have the same priority.  With the post and HoughLinesP streams at high priority their few
         // workgroups were placed ahead of a front kernel's thousands a little sooner (327 k against 320 k frames/s at
@@ -232,8 +251,6 @@ int setup_streams(lc_pipe *pp) {
         bool own = true;
         hipError_t e = hipStreamCreateWithFlags(&pp->st_edge, hipStreamNonBlocking);
         if (e == hipSuccess) mine.push_back(pp->st_edge);
-        const char *da = getenv("LANECV_LINES_DEFER");      // diagnostics: 0 / 1 / 2, see defer_after
-        if (da && da[0] >= '0' && da[0] <= '2') pp->defer_after = da[0] - '0';
         const char *pr = getenv("LANECV_LINES_PRIORITY");   // diagnostics: 0 keeps HoughLinesP on the edge stream
         if (e == hipSuccess && p.want_segments && !(pr && pr[0] == '0')) {
             pp->st_lines = picker.pick(mine, &own);
@@ -247,7 +264,7 @@ int setup_streams(lc_pipe *pp) {
         // front kernel then starts at once and they run beside it (LANECV_POST_STREAM=0: keep them on st_edge)
         pp->st_post = pp->st_edge;
         const char *po = getenv("LANECV_POST_STREAM");
-        if (p.nslots > 1 && !(po && po[0] == '0')) {
+        if (pp->banks.size() > 1 && !(po && po[0] == '0')) {
             hipStream_t st = picker.pick(mine, &own);
             if (st && own) { pp->st_post = st; mine.push_back(st); }
             else {                                  // no queue of its own: behind the front kernels, as with one slot
@@ -256,11 +273,9 @@ int setup_streams(lc_pipe *pp) {
             }
         }
         if (own_lines) {
-            hipDeviceProp_t prop;
             int want = 1;
-            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) pp->cu_count = prop.multiProcessorCount;
             if (pp->cu_count > 0)
-                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * pp->cu_count / p.max_batch, p.nslots - 1), 3));
+                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * pp->cu_count / pp->bank_frames, (int)pp->banks.size() - 1), 3));
             const char *ns = getenv("LANECV_LINES_STREAMS");
             if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
             for (int k = 1; k < want; k++) {
@@ -269,45 +284,42 @@ int setup_streams(lc_pipe *pp) {
                 else { if (st) picker.rejected.push_back(st); pp->shared_queues++; break; }
             }
         }
-        // with the post stream HoughLinesP starts as soon as its points are there (they are late enough: the short
-        // kernels wait for room beside the next front kernel); deferring it behind the next front kernel on top
-        // only ties it to the host's next submit
-        if (pp->st_post != pp->st_edge && !(da && da[0] >= '0' && da[0] <= '2')) pp->defer_after = 0;
     }
     return LC_OK;
 }
 
-int setup_slots(lc_pipe *pp) {
+int setup_banks(lc_pipe *pp) {
     const lc_pipe_params &p = pp->p;
     const bool hough = p.want_accumulator || p.want_segments;
+    const int B = p.max_batch, G = pp->parts, segcap = std::max(p.seg_capacity, 1);
     int rc;
+    pp->banks.resize((p.nslots + G - 1) / G);
     pp->slots.resize(p.nslots);
-    for (Slot &s : pp->slots) {
+    for (size_t bi = 0; bi < pp->banks.size(); bi++) {
+        Bank &bk = pp->banks[bi];
+        bk.parts = std::min(G, p.nslots - (int)bi * G);
+        const int frames = bk.parts * B;
         hipError_t e;
-        for (auto &ev : s.ev) {
+        for (auto &ev : bk.ev) {
             e = hipEventCreate(&ev);
             if (e != hipSuccess) return fail(LC_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e));
         }
-        if ((rc = s.w.init_images(p.width, p.height, p.max_batch, true, p.keep_intermediates != 0, true))) return rc;
-        if (pp->resizes && (rc = s.w.src_in.alloc((size_t)p.max_batch * pp->src_frame_bytes))) return rc;
+        Work &w = bk.w;
+        if ((rc = w.init_images(p.width, p.height, frames, true, p.keep_intermediates != 0, true))) return rc;
+        if (pp->resizes && (rc = w.src_in.alloc((size_t)frames * pp->src_frame_bytes))) return rc;
         // frames the streaming front kernel cannot take pass through a gated gray image
-        if (pp->has_gate && !s.w.gray.p && !front_stream_supported(pp->g) &&
-            (rc = s.w.gray.alloc((size_t)p.max_batch * p.width * p.height))) return rc;
+        if (pp->has_gate && !w.gray.p && !front_stream_supported(pp->g) && (rc = w.gray.alloc((size_t)frames * p.width * p.height))) return rc;
         if (hough || p.want_points) {
             // point list capacity per frame: an eighth of the pixels (a Canny map inside an ROI stays far below)
             int cap = std::max(1024, (int)std::min<size_t>((size_t)p.width * p.height, (size_t)p.width * p.height / 8 + 1024));
-            if ((rc = s.w.init_points(cap))) return rc;
+            if ((rc = w.init_points(cap))) return rc;
+            HIP_TRY(hipMemset(w.npoints.p, 0, sizeof(int) * (size_t)frames));
         }
-        if (hough) {
-            if ((rc = s.w.init_hough(p.rho, p.theta, std::max(p.seg_capacity, 1), p.want_accumulator != 0, p.want_segments != 0, pp->st_edge))) {
-                return rc;
-            }
-        }
-        const int segcap = std::max(p.seg_capacity, 1);
-        s.w.seg_cap = segcap;
-        if ((rc = s.w.init_results(segcap))) return rc;
+        if (hough && (rc = w.init_hough(p.rho, p.theta, segcap, p.want_accumulator != 0, p.want_segments != 0, pp->st_edge))) return rc;
+        w.seg_cap = segcap;
+        if ((rc = w.init_results(segcap, bk.parts))) return rc;
         void *hp = nullptr;
-        const size_t res_ints = s.w.res_head + (size_t)p.max_batch * segcap * 4;
+        const size_t res_ints = w.res_head + (size_t)frames * segcap * 4;
         // mapped and coherent: the kernels store a batch's results into it directly (see below), and the host reads
         // them after the batch's last event
         if (hipHostMalloc(&hp, sizeof(int32_t) * res_ints, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
@@ -315,77 +327,29 @@ int setup_slots(lc_pipe *pp) {
             (void)hipGetLastError();
             if ((rc = lc_host_alloc_pinned(sizeof(int32_t) * res_ints, &hp))) return rc;
         }
-        s.h_res = (int32_t *)hp;
-        memset(s.h_res, 0, sizeof(int32_t) * s.w.res_head);
-        s.h_segcount = s.h_res; s.h_rounds = s.h_res + p.max_batch; s.h_status = s.h_res + 2 * (size_t)p.max_batch;
-        s.h_seg = s.h_res + s.w.res_head;
+        bk.h_res = (int32_t *)hp;
+        memset(bk.h_res, 0, sizeof(int32_t) * w.res_head);
         // What goes back per batch is a few hundred bytes per frame, written once: the kernels store it into the
         // pinned block directly, which takes a copy and its launch off the HoughLinesP stream
-        // (LANECV_RESULT_COPY=1 keeps the device block and the copy).
+        // (LANECV_RESULT_COPY=1 keeps the device block and the copy; banks then hold one slot each).
         const char *rc_env = getenv("LANECV_RESULT_COPY");
         void *dp = nullptr;
-        if (!(rc_env && rc_env[0] == '1') && hipHostGetDevicePointer(&dp, s.h_res, 0) == hipSuccess && dp) {
+        if (!(rc_env && rc_env[0] == '1') && hipHostGetDevicePointer(&dp, bk.h_res, 0) == hipSuccess && dp) {
             int32_t *d = (int32_t *)dp;
-            s.w.r_segcount = d; s.w.r_rounds = d + p.max_batch; s.w.r_status = d + 2 * (size_t)p.max_batch; s.w.r_seg = d + s.w.res_head;
-            s.zero_copy = true;
+            w.r_segcount = d; w.r_rounds = d + frames; w.r_status = d + 2 * (size_t)frames; w.r_seg = d + w.res_head;
+            bk.zero_copy = true;
+        } else if (bk.parts > 1) {
+            return fail(LC_EHIP, "the pinned result block of a bank of %d slots cannot be mapped into the GPU's address space "
+                        "(LANECV_NO_GROUPS=1 configures one slot per bank)", bk.parts);
         }
-    }
-    return LC_OK;
-}
-
-int setup_groups(lc_pipe *pp) {
-    const lc_pipe_params &p = pp->p;
-    int rc;
-    {
-        // groups of slots with one HoughLinesP launch (see lc_pipe::Group): for batches that leave CUs free, when there
-        // are slots enough to fill one group while another one's launch runs
-        bool all_zero_copy = true;
-        for (Slot &s : pp->slots) all_zero_copy = all_zero_copy && s.zero_copy;
-        const char *ge = getenv("LANECV_NO_GROUPS");
-        int G = 1;
-        if (p.want_segments && all_zero_copy && !ge && 2 * p.max_batch <= pp->cu_count && p.nslots >= 4)
-            G = std::max(1, std::min(p.nslots / 2, pp->cu_count / p.max_batch));
-        if (G > 1) {
-            pp->group_size = G;
-            const int B = p.max_batch, segcap = std::max(p.seg_capacity, 1);
-            const size_t words = pp->g.rowplane_words();
-            pp->groups.resize((p.nslots + G - 1) / G);
-            for (size_t gi = 0; gi < pp->groups.size(); gi++) {
-                lc_pipe::Group &grp = pp->groups[gi];
-                const int first = (int)gi * G, gs = std::min(G, p.nslots - first);
-                Work &w0 = pp->slots[first].w;
-                const size_t accn = (size_t)w0.hg.numangle * w0.hg.numrho, cap = (size_t)w0.nz_cap, nfr = (size_t)gs * B;
-                if ((rc = grp.nz.alloc(nfr * cap)) || (rc = grp.npoints.alloc(nfr)) || (rc = grp.fallback.alloc(nfr)) ||
-                    (rc = grp.rowplane.alloc(nfr * words)) || (rc = grp.acc_ppht.alloc(nfr * accn)) ||
-                    (p.want_accumulator && (rc = grp.acc_full.alloc(nfr * accn)))) return rc;
-                HIP_TRY(hipMemset(grp.rowplane.p, 0, sizeof(uint64_t) * nfr * words));
-                HIP_TRY(hipMemset(grp.npoints.p, 0, sizeof(int) * nfr));
-                const size_t head = 2 * nfr + 8 * (size_t)gs, ints = head + nfr * segcap * 4;
-                void *hp = nullptr, *dp = nullptr;
-                if (hipHostMalloc(&hp, sizeof(int32_t) * ints, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-                    hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess || !dp) {
-                    return fail(LC_EHIP, "pinned result block of a slot group failed");
-                }
-                grp.h_res = (int32_t *)hp; grp.d_res = (int32_t *)dp;
-                memset(grp.h_res, 0, sizeof(int32_t) * head);
-                for (int j = 0; j < gs; j++) {
-                    Slot &s = pp->slots[first + j];
-                    Work &w = s.w;
-                    const size_t fo = (size_t)j * B;      // the slot's first frame in the group's buffers
-                    w.nz.alias(grp.nz.p + fo * cap, (size_t)B * cap);
-                    w.npoints.alias(grp.npoints.p + fo, B);
-                    w.fallback.alias(grp.fallback.p + fo, B);
-                    w.rowplane.alias(grp.rowplane.p + fo * words, (size_t)B * words);
-                    w.acc_ppht.alias(grp.acc_ppht.p + fo * accn, (size_t)B * accn);
-                    if (p.want_accumulator) w.acc_full.alias(grp.acc_full.p + fo * accn, (size_t)B * accn);
-                    if (s.h_res) { (void)hipHostFree(s.h_res); s.h_res = nullptr; }
-                    s.group = (int)gi; s.gpos = j;
-                    s.h_segcount = grp.h_res + fo; s.h_rounds = grp.h_res + nfr + fo; s.h_status = grp.h_res + 2 * nfr + 8 * (size_t)j;
-                    s.h_seg = grp.h_res + head + fo * segcap * 4;
-                    w.r_segcount = grp.d_res + fo; w.r_rounds = grp.d_res + nfr + fo; w.r_status = grp.d_res + 2 * nfr + 8 * (size_t)j;
-                    w.r_seg = grp.d_res + head + fo * segcap * 4;
-                }
-            }
+        for (int j = 0; j < bk.parts; j++) {
+            Slot &s = pp->slots[bi * G + j];
+            s.bank = (int)bi; s.pos = j;
+            const size_t fo = (size_t)j * B;       // the slot's first frame in the bank's buffers
+            s.h_segcount = bk.h_res + fo; s.h_rounds = bk.h_res + frames + fo; s.h_status = bk.h_res + 2 * (size_t)frames + 8 * (size_t)j;
+            s.h_seg = bk.h_res + w.res_head + fo * segcap * 4;
+            e = hipEventCreate(&s.done);
+            if (e != hipSuccess) return fail(LC_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e));
         }
     }
     return LC_OK;
@@ -421,12 +385,15 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     pp->line_length = (int)lrint(p.min_line_length);
     pp->line_gap = (int)lrint(p.max_line_gap);
     if (const char *fv = getenv("LANECV_VOTE_FUSED")) pp->fuse_vote = fv[0] != '0';
-    pp->ppht_two_per_cu = p.want_segments && (size_t)p.width * p.height <= 2600000 && p.nslots >= 3;
+    pp->ppht_two_per_cu = p.want_segments && (size_t)p.width * p.height <= 2600000;    // (and three banks or more: setup_streams)
     if (const char *tp = getenv("LANECV_PPHT_TWO_PER_CU")) pp->ppht_two_per_cu = tp[0] != '0';   // diagnostics
 
     std::vector<uint64_t> bits;
-    if ((rc = setup_front_tables(pp)) || (rc = setup_roi(pp, p, bits)) || (rc = setup_skip_levels(pp, bits)) ||
-        (rc = setup_streams(pp)) || (rc = setup_slots(pp)) || (rc = setup_groups(pp))) {
+    if ((rc = setup_front_tables(pp))) { lc_pipe_destroy(pp); return rc; }
+    setup_layout(pp);
+    pp->banks.resize((p.nslots + pp->parts - 1) / pp->parts);     // (their number shapes the stream layout; filled in by setup_banks)
+    if (!getenv("LANECV_PPHT_TWO_PER_CU")) pp->ppht_two_per_cu = pp->ppht_two_per_cu && pp->banks.size() >= 3;
+    if ((rc = setup_roi(pp, p, bits)) || (rc = setup_skip_levels(pp, bits)) || (rc = setup_streams(pp)) || (rc = setup_banks(pp))) {
         lc_pipe_destroy(pp);
         return rc;
     }
@@ -449,13 +416,12 @@ int lc_pipe_destroy(lc_pipe *pipe) {
     if (pipe->st_lines) (void)hipStreamSynchronize(pipe->st_lines);
     for (hipStream_t st : pipe->st_lines_more) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (pipe->st_post && pipe->st_post != pipe->st_edge) { (void)hipStreamSynchronize(pipe->st_post); (void)hipStreamDestroy(pipe->st_post); }
-    for (Slot &s : pipe->slots) {
-        for (auto &ev : s.ev) if (ev) (void)hipEventDestroy(ev);
-        if (s.h_res) (void)hipHostFree(s.h_res);
+    for (Slot &s : pipe->slots) if (s.done) (void)hipEventDestroy(s.done);
+    for (Bank &bk : pipe->banks) {
+        for (auto &ev : bk.ev) if (ev) (void)hipEventDestroy(ev);
+        if (bk.h_res) (void)hipHostFree(bk.h_res);
     }
-    for (lc_pipe::Group &G : pipe->groups) {
-        if (G.h_res) (void)hipHostFree(G.h_res);
-    }
+    if (pipe->ev_base) (void)hipEventDestroy(pipe->ev_base);
     if (pipe->st_lines && pipe->st_lines != pipe->st_edge) (void)hipStreamDestroy(pipe->st_lines);
     if (pipe->st_edge) (void)hipStreamDestroy(pipe->st_edge);
     if (pipe->st_up) (void)hipStreamDestroy(pipe->st_up);

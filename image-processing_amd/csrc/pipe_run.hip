@@ -8,206 +8,182 @@ using namespace lanecv;
 
 namespace {
 
-void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after);
-void flush_group(lc_pipe *pp, int g);
+// an event that only the stage times need
+inline void stamp(lc_pipe *pp, Bank &bk, int ev, hipStream_t st) {
+    if (pp->timing) (void)hipEventRecord(bk.ev[ev], st);
+}
 
-void enqueue_back(lc_pipe *pp, Slot &s) {
-    Work &w = s.w;
+bool vote_is_fused(const lc_pipe *pp) { return pp->p.want_accumulator && pp->p.want_segments && pp->fuse_vote; }
+
+// One launch of a bank: which of its slots take part, and over how many of the bank's frames the kernels are launched
+// (from frame 0 up to the last frame of the last slot taking part; the frame set makes them skip the rest).
+struct Launch {
+    FrameSet fs{};
+    const uint8_t *src[MAX_PARTS] = {};
+    int nframes = 0;
+    int level = 0;
+};
+
+// What follows hysteresis on stream es: the masked edge map, the ordered point list and, for recipes that want the
+// accumulator without segments (or with LANECV_VOTE_FUSED=0), the vote kernel.
+void enqueue_post(lc_pipe *pp, Bank &bk, const Launch &L, hipStream_t es) {
+    Work &w = bk.w;
     const lc_pipe_params &p = pp->p;
-    const int n = s.nframes;
-    hipStream_t es = pp->st_post;
+    const int n = L.nframes;
     const bool hough = p.want_accumulator || p.want_segments;
     const bool points = hough || p.want_points;
-    if (!points) (void)hipMemsetAsync(w.rowcount.p, 0, sizeof(int) * (size_t)n * w.g.H, es);   // nobody consumes (and clears) the counts
+    // nobody consumes (and clears) the row counts: the slot's own rows, then
+    if (!points)
+        for (int j = 0; j < bk.parts; j++)
+            if (L.fs.count[j])
+                (void)hipMemsetAsync(w.rowcount.p + (size_t)j * p.max_batch * w.g.H, 0, sizeof(int) * (size_t)L.fs.count[j] * w.g.H, es);
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
-                    w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p);
-    if (s.level < pp->nlevels) {
-        // frames that were classified in full: the plane rows of the units no frame needs are cleared again, now that
-        // they have been read (a few workgroups that look at the flags and, nearly always, leave)
-        const FrontSplit clear = pp->split(s.level, 2, w.redo.p);
-        launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
-                     nullptr, nullptr, es, nullptr, nullptr, nullptr, w.rowflags.p, pp->fused_dec3(), pp->front_rows, &clear);
-    }
-    (void)hipEventRecord(s.ev[EV_EDGE], es);
-    if (points) launch_points(w.g, n, w.rowplane.p, w.rowcount.p, w.nz.p, w.nz_cap, w.npoints.p, w.r_status, es);
-    // grouped slots: the group's HoughLinesP launch covers every slot's full capacity, and waits for EV_POINTS only --
-    // the frames beyond this batch must read as empty by then
-    if (p.want_segments && pp->group_size > 1 && n < p.max_batch)
-        (void)hipMemsetAsync(w.npoints.p + n, 0, sizeof(int) * (size_t)(p.max_batch - n), es);
-    (void)hipEventRecord(s.ev[EV_POINTS], es);
+                    w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p, &L.fs);
+    stamp(pp, bk, EV_EDGE, es);
+    if (points) launch_points(w.g, n, w.rowplane.p, w.rowcount.p, w.nz.p, w.nz_cap, w.npoints.p, w.r_status, es, &L.fs);
     // The full-vote accumulator depends only on the point list.  With segments wanted, the HoughLinesP kernel
-    // produces it on the side (its helper wavefronts, from the same LDS-resident set-up) and the vote kernel
-    // only runs for the frames that kernel flags; it sits between the two HoughLinesP steps because the
-    // general one permutes the point list.  Stage times: VOTE = that flagged launch, LINES = both steps.
-    const bool vote_fused = p.want_accumulator && p.want_segments && pp->fuse_vote;
-    if (p.want_accumulator && !vote_fused)
-        launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, nullptr, es);
-    if (!vote_fused) (void)hipEventRecord(s.ev[EV_VOTE], es);
-    if (p.want_segments && pp->group_size > 1) {
-        // grouped slots: the HoughLinesP launch waits for the group's last slot (or for a wait on one of its slots)
-        lc_pipe::Group &G = pp->groups[s.group];
-        G.pending.push_back((int)(&s - &pp->slots[0]));
-        s.lines_pending = true;
-        const int first = s.group * pp->group_size, gs = std::min(pp->group_size, (int)pp->slots.size() - first);
-        if ((int)G.pending.size() >= gs) flush_group(pp, s.group);
-        return;
+    // produces it on the side (in the LDS array it then counts in); otherwise the vote kernel does, here.
+    const bool own_vote = p.want_accumulator && !vote_is_fused(pp);
+    if (own_vote) {
+        stamp(pp, bk, EV_POINTS, es);
+        launch_vote(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_full.p, nullptr, es, &L.fs);
     }
-    if (p.want_segments && pp->st_lines != es && pp->defer_after && pp->slots.size() > 1) pp->deferred = (int)(&s - &pp->slots[0]);
-    else enqueue_lines(pp, s, nullptr);
 }
 
-// One HoughLinesP launch for the slots of a group whose points are queued: their frames lie back to back in the
-// group's buffers (slot j at frame j * max_batch), the launch covers them all.  What the launch has to report about a
-// frame it raises in the status words of the frame's own slot (the slots' status blocks lie back to back too), which
-// that slot's hysteresis kernel zeroed earlier on in the batch: a slot never sees another slot's flags, and nothing is
-// cleared from the host.
-void flush_group(lc_pipe *pp, int g) {
-    lc_pipe::Group &G = pp->groups[g];
-    if (G.pending.empty()) return;
+// HoughLinesP of a launch's frames on stream ls, and the events that mark its slots done
+void enqueue_lines(lc_pipe *pp, Bank &bk, Slot *first, const Launch &L, hipStream_t ls) {
+    Work &w = bk.w;
     const lc_pipe_params &p = pp->p;
-    const int first = g * pp->group_size, m = (int)G.pending.size();
-    bool prefix = true;
-    for (int i = 0; i < m; i++) prefix = prefix && G.pending[i] == first + i;
-    if (!prefix) {      // slots used out of order: a launch each
-        for (int k : G.pending) { pp->slots[k].lines_pending = false; enqueue_lines(pp, pp->slots[k], nullptr); }
-        G.pending.clear();
-        return;
-    }
-    Slot &lead = pp->slots[first];
-    Work &w = lead.w;
-    const int n_total = (m - 1) * p.max_batch + pp->slots[first + m - 1].nframes;
-    const bool vote_fused = p.want_accumulator && p.want_segments && pp->fuse_vote;
-    const unsigned turn = pp->lines_turn++ % (unsigned)(1 + pp->st_lines_more.size());
-    hipStream_t ls = turn ? pp->st_lines_more[turn - 1] : pp->st_lines;
-    for (int i = 0; i < m; i++) {
-        Slot &s = pp->slots[first + i];
-        if (ls != pp->st_post) (void)hipStreamWaitEvent(ls, s.ev[(p.want_accumulator && !vote_fused) ? EV_VOTE : EV_POINTS], 0);
-    }
-    for (int i = 0; i < m; i++) (void)hipEventRecord(pp->slots[first + i].ev[EV_LSTART], ls);
-    const bool fast = launch_ppht_fast(w.g, n_total, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
-                                       p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
-                                       w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls,
-                                       (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false,
-                                       2 * n_total > pp->cu_count ? 0 : 8, p.max_batch);
-    if (pp->ppht_full_for > 0) pp->ppht_full_for--;
-    launch_ppht_general(w.g, n_total, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
-                        p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
-                        fast ? w.fallback.p : nullptr, ls, vote_fused ? w.acc_full.p : nullptr, p.max_batch);
-    for (int i = 0; i < m; i++) {
-        Slot &s = pp->slots[first + i];
-        (void)hipEventRecord(s.ev[EV_LINES], ls);
-        s.end_ev = EV_LINES;
-        s.lines_pending = false;
-    }
-    G.pending.clear();
-}
-
-// HoughLinesP step and the copy of the batch's results; `after` (may be null) is a later batch's event to start behind
-void enqueue_lines(lc_pipe *pp, Slot &s, hipEvent_t after) {
-    Work &w = s.w;
-    const lc_pipe_params &p = pp->p;
-    const int n = s.nframes;
-    hipStream_t es = pp->st_post;
-    const bool vote_fused = p.want_accumulator && p.want_segments && pp->fuse_vote;
-    hipStream_t ls = es;   // the stream the batch finishes on
+    const bool vote_fused = vote_is_fused(pp);
+    stamp(pp, bk, EV_LSTART, ls);
+    bool fast = false;
     if (p.want_segments) {
-        const unsigned turn = pp->lines_turn++ % (unsigned)(1 + pp->st_lines_more.size());
-        ls = turn ? pp->st_lines_more[turn - 1] : pp->st_lines;
-        // (a stand-alone vote kernel reads the point list the general kernel permutes: behind it, then)
-        if (ls != es) (void)hipStreamWaitEvent(ls, s.ev[(p.want_accumulator && !vote_fused) ? EV_VOTE : EV_POINTS], 0);
-        if (ls != es && after) (void)hipStreamWaitEvent(ls, after, 0);
-        (void)hipEventRecord(s.ev[EV_LSTART], ls);
-        const bool fast = launch_ppht_fast(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
-                                           p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
-                                           w.fallback.p, w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls,
-                                           (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false,
-                                           2 * p.max_batch > pp->cu_count ? 0 : 8);
+        fast = launch_ppht_fast(w.g, L.nframes, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
+                                p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status, w.fallback.p,
+                                w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls,
+                                (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false,
+                                2 * L.nframes > pp->cu_count ? 0 : 8, p.max_batch, &L.fs);
         if (pp->ppht_full_for > 0) pp->ppht_full_for--;
-        // one launch for the frames the fast kernel flagged: their full-vote accumulator first (the general kernel
-        // permutes the point list), then HoughLinesP with all state in global memory.  No events in between: every
-        // packet on this stream is on the critical path.
-        launch_ppht_general(w.g, n, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p,
-                            p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status,
-                            fast ? w.fallback.p : nullptr, ls, vote_fused ? w.acc_full.p : nullptr);
-        (void)hipEventRecord(s.ev[EV_LINES], ls);
-    } else {
-        (void)hipEventRecord(s.ev[EV_LSTART], ls);
-        (void)hipEventRecord(s.ev[EV_LINES], ls);
+        // Frames the fast kernel cannot do (more points than fit a CU's LDS) are rare: it raises a status word of their
+        // slot and lc_pipe_wait launches the general kernel then.  No packet that is not needed: every one on this
+        // stream is on the critical path.  (More than 64 angles or frames wider than 4096: the general kernel for all,
+        // slot by slot -- it knows no frame sets.)
+        if (!fast)
+            for (int j = 0; j < bk.parts; j++) {
+                if (!L.fs.count[j]) continue;
+                const size_t fo = (size_t)j * p.max_batch, accn = (size_t)w.hg.numangle * w.hg.numrho;
+                launch_ppht_general(w.g, L.fs.count[j], w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(),
+                                    w.tab.p, w.hg.numangle, w.hg.numrho, w.acc_ppht.p + fo * accn, p.threshold, pp->line_length, pp->line_gap,
+                                    w.r_seg + fo * w.seg_cap * 4, w.seg_cap, w.r_segcount + fo, w.r_status + 8 * j, nullptr, ls,
+                                    vote_fused ? w.acc_full.p + fo * accn : nullptr);
+            }
     }
-    s.end_ev = EV_LINES;
-    if (!s.zero_copy) {   // one copy: counts, rounds, status and (if wanted) the segments of the n frames
-        const size_t res_ints = w.res_head + (p.want_segments ? (size_t)n * w.seg_cap * 4 : 0);
-        (void)hipMemcpyAsync(s.h_res, w.resblock.p, sizeof(int32_t) * res_ints, hipMemcpyDeviceToHost, ls);
-        (void)hipEventRecord(s.ev[EV_END], ls);
-        s.end_ev = EV_END;
+    stamp(pp, bk, EV_LINES, ls);
+    if (!bk.zero_copy) {   // (banks of one slot) one copy: counts, rounds, status and (if wanted) the segments of the n frames
+        const size_t res_ints = w.res_head + (p.want_segments ? (size_t)L.nframes * w.seg_cap * 4 : 0);
+        (void)hipMemcpyAsync(bk.h_res, w.resblock.p, sizeof(int32_t) * res_ints, hipMemcpyDeviceToHost, ls);
+        stamp(pp, bk, EV_END, ls);
+    }
+    for (int j = 0; j < bk.parts; j++) {
+        if (!L.fs.count[j]) continue;
+        Slot &s = first[j];
+        (void)hipEventRecord(s.done, ls);
+        s.fast_lines = fast;
     }
 }
 
-// from_host: the frames were just queued for copy on st_up (EV_START is recorded there)
-int enqueue_all(lc_pipe *pp, Slot &s, bool from_host) {
-    Work &w = s.w;
+hipStream_t next_lines_stream(lc_pipe *pp) {
+    if (!pp->p.want_segments) return pp->st_post;
+    const unsigned turn = pp->lines_turn++ % (unsigned)(1 + pp->st_lines_more.size());
+    return turn ? pp->st_lines_more[turn - 1] : pp->st_lines;
+}
+
+// Queues the kernels for the bank's pending slots: one launch each over all their frames.
+int launch_bank(lc_pipe *pp, int bi) {
+    Bank &bk = pp->banks[bi];
+    Work &w = bk.w;
     const lc_pipe_params &p = pp->p;
-    const int n = s.nframes;
-    hipStream_t es = pp->st_edge;
-    if (from_host) {
-        HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], pp->st_up));
-        HIP_TRY(hipStreamWaitEvent(es, s.ev[EV_UPLOADED], 0));
-    } else {
-        HIP_TRY(hipEventRecord(s.ev[EV_START], es));
-        HIP_TRY(hipEventRecord(s.ev[EV_UPLOADED], es));
+    Slot *first = &pp->slots[(size_t)bi * pp->parts];
+    Launch L;
+    L.fs.per_part = p.max_batch;
+    bool older = false, from_host = false;          // an earlier launch of this bank may still be running / frames are being uploaded
+    for (int j = 0; j < bk.parts; j++) {
+        const Slot &s = first[j];
+        L.src[j] = s.input;
+        older = older || (s.busy && !s.pending);
+        if (!s.pending) continue;
+        L.fs.count[j] = s.nframes;
+        L.nframes = j * p.max_batch + s.nframes;
+        from_host = from_host || s.from_host;
     }
-    HIP_TRY(hipEventRecord(s.ev[EV_ESTART], es));
+    if (L.nframes == 0) return LC_OK;
+    const int n = L.nframes;
+    hipStream_t es = pp->st_edge, ps = pp->st_post;
+    if (from_host) {
+        HIP_TRY(hipEventRecord(bk.ev[EV_UPLOADED], pp->st_up));     // behind the copies of every pending slot
+        HIP_TRY(hipStreamWaitEvent(es, bk.ev[EV_UPLOADED], 0));
+    } else {
+        stamp(pp, bk, EV_START, es);
+        stamp(pp, bk, EV_UPLOADED, es);
+    }
+    stamp(pp, bk, EV_ESTART, es);
     // the exact reduction by three needs no pass of its own: the front kernel reads the source pixels it keeps
     const bool fused_resize = pp->fused_dec3();
-    if (pp->resizes && !fused_resize) {
-        launch_resize_linear(s.input, pp->src_w, pp->src_h, 3, n, w.bgr.p, w.g.W, w.g.H, pp->resize_tab.p, pp->resize_area2, es, pp->resize_dec3);
-        s.input = w.bgr.p;
-        s.input_bytes = (size_t)n * 3 * w.npix;
+    if (pp->resizes && !fused_resize) {             // (banks of one slot)
+        launch_resize_linear(L.src[0], pp->src_w, pp->src_h, 3, n, w.bgr.p, w.g.W, w.g.H, pp->resize_tab.p, pp->resize_area2, es, pp->resize_dec3);
+        L.src[0] = first[0].input = w.bgr.p;
     }
     if (pp->level > 0 && pp->nlevels > 0) {
         if (pp->level_hold > 0) pp->level_hold--;
         else { pp->level--; pp->level_hold = 0; }     // try one level in again
     }
-    s.level = pp->nlevels > 0 ? pp->level : 0;
-    const bool skipping = s.level < pp->nlevels;
-    const FrontSplit skip = pp->split(s.level, 1, nullptr), again = pp->split(pp->nlevels, 0, w.redo.p);
+    L.level = pp->nlevels > 0 ? pp->level : 0;
+    // (no clearing of plane rows beside a launch that may still be reading them: stay at the looser level this once)
+    if (older && L.level < bk.planes_level) L.level = std::min(bk.planes_level, pp->nlevels);
+    const bool skipping = L.level < pp->nlevels;
+    const FrontSplit skip = pp->split(L.level, 1, nullptr);
+    // (what the tiled kernel may read of a one-slot bank's frames)
+    const size_t src_bytes = (size_t)n * (pp->resizes && !fused_resize ? 3 * w.npix : pp->src_frame_bytes);
     if (pp->nlevels > 0) {
-        if (s.level < s.planes_level) {      // back at a tighter level: the plane rows of the units it does not need go first
-            // (for every frame the slot can hold, not just this batch's: an earlier, larger batch at the looser level
-            // left its bits in the frames behind this batch's too, and a later batch at this level would flood from them)
-            const FrontSplit clear_all = pp->split(s.level, 2, pp->ones.p);
-            launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, p.max_batch, pp->low, pp->high, w.planeS.p, w.planeW.p,
-                         w.wake.p, nullptr, nullptr, es, nullptr, nullptr, nullptr, w.rowflags.p, pp->fused_dec3(), pp->front_rows,
-                         &clear_all);
+        if (L.level < bk.planes_level) {
+            // Back at a tighter level, or after a batch some of whose frames had to be classified in full (see
+            // lc_pipe_wait): the plane rows of the units this level does not need go first.  For every frame the bank
+            // holds, not just this launch's: an earlier, larger batch left its bits in the frames behind this one's
+            // too, and a later batch at this level would flood from them.
+            const FrontSplit clear_all = pp->split(L.level, 2, pp->ones.p);
+            launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, bk.parts * p.max_batch, pp->low, pp->high,
+                         w.planeS.p, w.planeW.p, w.wake.p, nullptr, nullptr, es, nullptr, nullptr, nullptr, w.rowflags.p, fused_resize,
+                         pp->front_rows, &clear_all);
         }
-        s.planes_level = s.level;
+        bk.planes_level = L.level;
     }
-    launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
+    launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
                  pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize, pp->front_rows,
-                 pp->nlevels > 0 ? &skip : nullptr);
-    HIP_TRY(hipEventRecord(s.ev[EV_FRONT], es));
-    if (pp->deferred >= 0 && pp->defer_after == 1) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_FRONT]); pp->deferred = -1; }
-    hipStream_t ps = pp->st_post;
-    if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, s.ev[EV_FRONT], 0));
-    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status);
-    if (skipping) {
-        // frames for which the units near the ROI alone do not settle its edges: all units again, and their hysteresis
-        // (both launches leave at once for the other frames, which is nearly always all of them)
-        const lc_pipe::SkipLevel &L = pp->levels[s.level];
-        launch_ring_check(w.g, n, w.planeS.p, w.planeW.p, L.ring_words.p, L.n_ring_words, L.ring_code.p, w.redo.p, w.r_status, ps,
-                          w.r_rounds);
-        launch_front(s.input, s.input_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
-                     w.wake.p, nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p,
-                     fused_resize, pp->front_rows, &again);
-        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p);
-    }
-    HIP_TRY(hipEventRecord(s.ev[EV_HYST], ps));
-    if (pp->deferred >= 0) { enqueue_lines(pp, pp->slots[pp->deferred], s.ev[EV_HYST]); pp->deferred = -1; }
-    enqueue_back(pp, s);
+                 pp->nlevels > 0 ? &skip : nullptr, &L.fs, L.src);
+    if (ps != es || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_FRONT], es));
+    if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, bk.ev[EV_FRONT], 0));
+    // Hysteresis; with an ROI level active the frame's workgroup then proves that the units classified settle the ROI's
+    // edges, or flags the frame (rare): lc_pipe_wait classifies flagged frames again in full and redoes what follows.
+    const lc_pipe::SkipLevel *SL = skipping ? &pp->levels[L.level] : nullptr;
+    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status, nullptr, SL ? SL->ring_words.p : nullptr,
+                      SL ? SL->n_ring_words : 0, SL ? SL->ring_code.p : nullptr, w.redo.p, &L.fs);
+    stamp(pp, bk, EV_HYST, ps);
+    enqueue_post(pp, bk, L, ps);
+    hipStream_t ls = next_lines_stream(pp);
+    const int ready = (p.want_accumulator && !vote_is_fused(pp)) ? EV_VOTE : EV_POINTS;
+    if (ls != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[ready], ps));
+    if (pp->timing && ready == EV_POINTS && !vote_is_fused(pp)) (void)hipEventRecord(bk.ev[EV_VOTE], ps);
+    // (a stand-alone vote kernel reads the point list the general HoughLinesP kernel permutes: HoughLinesP behind it, then)
+    if (ls != ps) HIP_TRY(hipStreamWaitEvent(ls, bk.ev[ready], 0));
+    enqueue_lines(pp, bk, first, L, ls);
     HIP_TRY(hipGetLastError());
-    s.busy = true;
-    s.timed = true;
+    for (int j = 0; j < bk.parts; j++) {
+        if (!L.fs.count[j]) continue;
+        first[j].pending = false;
+        first[j].level = L.level;
+        first[j].timed = pp->timing;
+    }
     return LC_OK;
 }
 
@@ -237,12 +213,96 @@ int get_slot(lc_pipe *pipe, int slot, Slot **out) {
     return LC_OK;
 }
 
+// the slot's own part of its bank's input buffer
+uint8_t *own_input(lc_pipe *pipe, const Slot &s) {
+    Work &w = pipe->banks[s.bank].w;
+    return (pipe->resizes ? w.src_in.p : w.bgr.p) + (size_t)s.pos * pipe->p.max_batch * pipe->src_frame_bytes;
+}
+
+// a submit: the slot joins its bank's pending ones, and the bank's kernels are queued once they are all there
+int submit(lc_pipe *pipe, Slot &s) {
+    s.busy = s.pending = true;
+    const Bank &bk = pipe->banks[s.bank];
+    const Slot *first = &pipe->slots[(size_t)s.bank * pipe->parts];
+    int pending = 0;
+    for (int j = 0; j < bk.parts; j++) pending += first[j].pending ? 1 : 0;
+    if (pending < bk.parts) return LC_OK;
+    const int rc = launch_bank(pipe, s.bank);
+    if (rc) s.busy = s.pending = false;
+    return rc;
+}
+
+// Polls `ev` and gives up after LANECV_WAIT_TIMEOUT_S seconds (default 120; 0 = block in hipEventSynchronize for ever)
+// with a report of which of the pipeline's slots have finished: a pipeline whose streams starve each other (more
+// streams in the process than hardware queues, see lc_pipe_create) then fails loudly instead of hanging its caller.
+int wait_event(lc_pipe *pipe, int slot, hipEvent_t ev) {
+    static const double wait_limit = getenv("LANECV_WAIT_TIMEOUT_S") ? atof(getenv("LANECV_WAIT_TIMEOUT_S")) : 120.0;
+    if (!(wait_limit > 0)) {
+        HIP_TRY(hipEventSynchronize(ev));
+        return LC_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return LC_OK;
+        if (q != hipErrorNotReady) HIP_TRY(q);
+        if ((spins & 63) != 63) continue;                     // the clock is read every 64th query
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > wait_limit) {
+            std::string rep;
+            for (size_t k = 0; k < pipe->slots.size(); k++) {
+                Slot &o = pipe->slots[k];
+                rep += " slot" + std::to_string(k) + (o.busy ? (o.pending ? "(pending)" : "*") : "") + ":";
+                rep += hipEventQuery(o.done) == hipSuccess ? '1' : '0';
+            }
+            if (pipe->timing)
+                for (size_t b = 0; b < pipe->banks.size(); b++) {
+                    rep += " bank" + std::to_string(b) + ":";
+                    for (auto &e : pipe->banks[b].ev) rep += hipEventQuery(e) == hipSuccess ? '1' : '0';
+                }
+            (void)hipGetLastError();
+            return fail(LC_EHIP, "wait: slot %d not finished after %.0f s; done events fired per slot (* = in flight)%s%s", slot, wait_limit,
+                        pipe->timing ? ", stage events per bank (START UPLOADED FRONT HYST EDGE POINTS VOTE LINES END ESTART LSTART VSTART):" : ":",
+                        rep.c_str());
+        }
+        if (waited > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));   // a batch takes about a millisecond
+    }
+}
+
+// Frames of slot s whose edges the units near the ROI did not settle (flagged by the hysteresis kernel; the host has
+// just seen the slot's status word): all units of those frames once more, their hysteresis, and then everything behind
+// it for the slot's whole batch -- finalize rewrites what changed, the point lists and HoughLinesP are made again.  On
+// the post stream, in order behind whatever else is queued there.  The slot's input must still be where it was
+// submitted.
+void enqueue_repair(lc_pipe *pp, Slot &s) {
+    Bank &bk = pp->banks[s.bank];
+    Work &w = bk.w;
+    const lc_pipe_params &p = pp->p;
+    Slot *first = &pp->slots[(size_t)s.bank * pp->parts];
+    Launch L;
+    L.fs.per_part = p.max_batch;
+    for (int j = 0; j < bk.parts; j++) L.src[j] = first[j].input;
+    L.fs.count[s.pos] = s.nframes;
+    L.nframes = s.pos * p.max_batch + s.nframes;
+    L.level = pp->nlevels;
+    hipStream_t ps = pp->st_post;
+    const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
+    const size_t src_bytes = (size_t)L.nframes * (pp->resizes && !pp->fused_dec3() ? 3 * w.npix : pp->src_frame_bytes);
+    launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, L.nframes, pp->low, pp->high,
+                 w.planeS.p, w.planeW.p, w.wake.p, nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p,
+                 w.rowflags.p, pp->fused_dec3(), pp->front_rows, &again, &L.fs, L.src);
+    launch_hysteresis(w.g, L.nframes, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs);
+    enqueue_post(pp, bk, L, ps);
+    enqueue_lines(pp, bk, first, L, ps);
+    // the full passes stored plane rows in units the slot's level does not classify: cleared before the bank's next launch
+    bk.planes_level = pp->nlevels;
+}
+
 }  // namespace
 
 namespace lanecv {
 void pipe_flush_pending(lc_pipe *pipe) {
-    if (pipe->deferred >= 0) { enqueue_lines(pipe, pipe->slots[pipe->deferred], nullptr); pipe->deferred = -1; }
-    for (size_t g = 0; g < pipe->groups.size(); g++) flush_group(pipe, (int)g);
+    for (size_t b = 0; b < pipe->banks.size(); b++) (void)launch_bank(pipe, (int)b);
 }
 }  // namespace lanecv
 
@@ -255,13 +315,13 @@ int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nf
     if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "submit: bad frames argument");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
     s->nframes = nframes;
-    s->input_bytes = (size_t)nframes * pipe->src_frame_bytes;
-    uint8_t *own = pipe->resizes ? s->w.src_in.p : s->w.bgr.p;
+    uint8_t *own = own_input(pipe, *s);
     s->input = own;
+    s->from_host = true;
     if ((rc = upload_stream(pipe))) return rc;
-    HIP_TRY(hipEventRecord(s->ev[EV_START], pipe->st_up));
-    HIP_TRY(hipMemcpyAsync(own, host_bgr, s->input_bytes, hipMemcpyHostToDevice, pipe->st_up));
-    return enqueue_all(pipe, *s, true);
+    if (pipe->timing) HIP_TRY(hipEventRecord(pipe->banks[s->bank].ev[EV_START], pipe->st_up));
+    HIP_TRY(hipMemcpyAsync(own, host_bgr, (size_t)nframes * pipe->src_frame_bytes, hipMemcpyHostToDevice, pipe->st_up));
+    return submit(pipe, *s);
 }
 
 int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nframes) {
@@ -272,9 +332,9 @@ int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nfra
     if (((uintptr_t)dev_bgr & 15) != 0) return fail(LC_EINVAL, "submit: device frames must be 16-byte aligned");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
     s->nframes = nframes;
-    s->input_bytes = (size_t)nframes * pipe->src_frame_bytes;
     s->input = (const uint8_t *)dev_bgr;
-    return enqueue_all(pipe, *s, false);
+    s->from_host = false;
+    return submit(pipe, *s);
 }
 
 int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count) {
@@ -282,41 +342,14 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     int rc;
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
-    if (pipe->deferred == slot) { enqueue_lines(pipe, *s, nullptr); pipe->deferred = -1; }
-    if (s->lines_pending) flush_group(pipe, s->group);
-    // The wait polls the batch's last event and gives up after LANECV_WAIT_TIMEOUT_S seconds (default 120; 0 = block
-    // in hipEventSynchronize for ever) with a report of which of the pipeline's events have fired, per slot, in the
-    // order of the EV_ enumeration: a pipeline whose streams starve each other (more streams in the process than
-    // hardware queues, see lc_pipe_create) then fails loudly instead of hanging its caller.
-    static const double wait_limit = getenv("LANECV_WAIT_TIMEOUT_S") ? atof(getenv("LANECV_WAIT_TIMEOUT_S")) : 120.0;
-    if (wait_limit > 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0;; spins++) {
-            const hipError_t q = hipEventQuery(s->ev[s->end_ev]);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) HIP_TRY(q);
-            if ((spins & 63) != 63) continue;                     // the clock is read every 64th query
-            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (waited > wait_limit) {
-                std::string rep;
-                for (size_t k = 0; k < pipe->slots.size(); k++) {
-                    Slot &o = pipe->slots[k];
-                    rep += " slot" + std::to_string(k) + (o.busy ? "*:" : ":");
-                    for (auto &ev : o.ev) rep += hipEventQuery(ev) == hipSuccess ? '1' : '0';
-                }
-                (void)hipGetLastError();
-                return fail(LC_EHIP, "wait: slot %d not finished after %.0f s; events fired (START UPLOADED FRONT HYST EDGE POINTS VOTE "
-                            "LINES END ESTART LSTART VSTART):%s", slot, wait_limit, rep.c_str());
-            }
-            if (waited > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));   // a batch takes about a millisecond
-        }
-    } else {
-        HIP_TRY(hipEventSynchronize(s->ev[s->end_ev]));
-    }
-    s->busy = false;
     const lc_pipe_params &p = pipe->p;
-    if (p.want_segments && s->h_status[2]) pipe->ppht_full_for = 64;   // a frame outgrew half a CU's LDS (see lc_pipe)
-    if (s->level < pipe->nlevels && s->h_status[3]) {                   // frames that needed the full pass after all
+    if (s->pending && (rc = launch_bank(pipe, s->bank))) return rc;      // its bank is not full: what is there goes now
+    if ((rc = wait_event(pipe, slot, s->done))) return rc;
+    // The common case ends here.  Two rare ones were left out of the submit so that it queues nothing that is not needed,
+    // and are made up for now that the host can see the batch's status words:
+    if (s->level < pipe->nlevels && s->h_status[3]) {
+        // frames the ROI scheme could not settle from the units near the ROI: classified in full, the batch's later
+        // stages made again
         int redone = 0;
         for (int i = 0; i < s->nframes; i++) redone += (s->h_rounds[i] >> 30) & 1;
         const char *ob = getenv("LANECV_SKIP_OFF_BATCHES");         // diagnostics / tests; 0 = never move a level out
@@ -325,18 +358,53 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
             pipe->level = s->level + 1;
             pipe->level_hold = off_batches;
         }
+        enqueue_repair(pipe, *s);
+        HIP_TRY(hipGetLastError());
+        if ((rc = wait_event(pipe, slot, s->done))) return rc;
     }
+    if (p.want_segments && s->fast_lines && s->h_status[4]) {
+        // frames with more edge points than the LDS-resident HoughLinesP kernel takes: the general kernel, for them
+        Work &w = pipe->banks[s->bank].w;
+        const bool vote_fused = vote_is_fused(pipe);
+        hipStream_t ps = pipe->st_post;
+        const size_t fo = (size_t)s->pos * p.max_batch, accn = (size_t)w.hg.numangle * w.hg.numrho;
+        launch_ppht_general(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
+                            w.hg.numangle, w.hg.numrho, w.acc_ppht.p + fo * accn, p.threshold, pipe->line_length, pipe->line_gap,
+                            w.r_seg + fo * w.seg_cap * 4, w.seg_cap, w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, ps,
+                            vote_fused ? w.acc_full.p + fo * accn : nullptr);
+        if (!pipe->banks[s->bank].zero_copy) {
+            const size_t res_ints = w.res_head + (size_t)s->nframes * w.seg_cap * 4;
+            HIP_TRY(hipMemcpyAsync(pipe->banks[s->bank].h_res, w.resblock.p, sizeof(int32_t) * res_ints, hipMemcpyDeviceToHost, ps));
+        }
+        HIP_TRY(hipEventRecord(s->done, ps));
+        HIP_TRY(hipGetLastError());
+        if ((rc = wait_event(pipe, slot, s->done))) return rc;
+    }
+    s->busy = false;
+    if (p.want_segments && s->h_status[2]) pipe->ppht_full_for = 64;   // a frame outgrew half a CU's LDS (see lc_pipe)
     if (p.want_segments || p.want_accumulator || p.want_points) {
         if (s->h_status[0])
             return fail(LC_ECAP, "a frame holds more edge points than the pipeline keeps per frame (%d): its point list, accumulator and "
-                        "segments are incomplete", s->w.nz_cap);
+                        "segments are incomplete", pipe->banks[s->bank].w.nz_cap);
         if (s->h_status[1])
             return fail(LC_EINVAL, "HoughLinesP: a vote fell outside the accumulator (the angle table does not fit the image size)");
     }
     if (p.want_segments) {
         if (seg_count) memcpy(seg_count, s->h_segcount, sizeof(int) * s->nframes);
-        if (seg_xyxy) memcpy(seg_xyxy, s->h_seg, sizeof(int32_t) * 4 * (size_t)s->nframes * s->w.seg_cap);
+        if (seg_xyxy) memcpy(seg_xyxy, s->h_seg, sizeof(int32_t) * 4 * (size_t)s->nframes * pipe->banks[s->bank].w.seg_cap);
     }
+    return LC_OK;
+}
+
+int lc_pipe_set_timing(lc_pipe *pipe, int on) {
+    if (!pipe) return fail(LC_EINVAL, "null pipeline");
+    if (on && !pipe->ev_base) {          // the origin of lc_pipe_event_times
+        HIP_TRY(hipSetDevice(pipe->ctx->device));
+        HIP_TRY(hipEventCreate(&pipe->ev_base));
+        HIP_TRY(hipEventRecord(pipe->ev_base, pipe->st_edge));
+        HIP_TRY(hipEventSynchronize(pipe->ev_base));
+    }
+    pipe->timing = on != 0;
     return LC_OK;
 }
 
@@ -346,29 +414,31 @@ int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
     if (!host_dst) return fail(LC_EINVAL, "null destination");
-    Work &w = s->w;
-    const void *src = nullptr;
-    size_t need = 0;
-    const size_t img = (size_t)s->nframes * w.npix;
+    Work &w = pipe->banks[s->bank].w;
+    const uint8_t *src = nullptr;
+    size_t need = 0, off = 0;
+    const size_t img = (size_t)s->nframes * w.npix, fo = (size_t)s->pos * pipe->p.max_batch;     // fo: the slot's first frame in the bank
+    const size_t accn = (size_t)w.hg.numangle * w.hg.numrho;
     switch (what) {
-        case LC_BUF_GRAY: src = w.inter ? w.gray.p : nullptr; need = img; break;
-        case LC_BUF_BLUR: src = (w.inter && pipe->p.blur) ? w.blur.p : nullptr; need = img; break;
-        case LC_BUF_EDGES: src = w.inter ? w.edges.p : nullptr; need = img; break;
-        case LC_BUF_MASKED: src = w.masked.p; need = img; break;
-        case LC_BUF_ACC: src = pipe->p.want_accumulator ? w.acc_full.p : nullptr;
-            need = sizeof(int32_t) * (size_t)s->nframes * w.hg.numangle * w.hg.numrho; break;
-        case LC_BUF_NPOINTS: src = (pipe->p.want_accumulator || pipe->p.want_segments || pipe->p.want_points) ? w.npoints.p : nullptr;
-            need = sizeof(int) * s->nframes; break;
+        case LC_BUF_GRAY: src = w.inter ? w.gray.p : nullptr; need = img; off = fo * w.npix; break;
+        case LC_BUF_BLUR: src = (w.inter && pipe->p.blur) ? w.blur.p : nullptr; need = img; off = fo * w.npix; break;
+        case LC_BUF_EDGES: src = w.inter ? w.edges.p : nullptr; need = img; off = fo * w.npix; break;
+        case LC_BUF_MASKED: src = w.masked.p; need = img; off = fo * w.npix; break;
+        case LC_BUF_ACC: src = pipe->p.want_accumulator ? reinterpret_cast<const uint8_t *>(w.acc_full.p) : nullptr;
+            need = sizeof(int32_t) * (size_t)s->nframes * accn; off = sizeof(int32_t) * fo * accn; break;
+        case LC_BUF_NPOINTS:
+            src = (pipe->p.want_accumulator || pipe->p.want_segments || pipe->p.want_points) ? reinterpret_cast<const uint8_t *>(w.npoints.p) : nullptr;
+            need = sizeof(int) * s->nframes; off = sizeof(int) * fo; break;
         case LC_BUF_RESIZED:
             if (pipe->fused_dec3())
                 return fail(LC_EINVAL, "the resized frames are not materialised when the reduction by three is fused into the edge "
                             "kernel; configure keep_intermediates to read them");
-            src = pipe->resizes ? w.bgr.p : nullptr; need = 3 * img; break;
+            src = pipe->resizes ? w.bgr.p : nullptr; need = 3 * img; off = 3 * fo * w.npix; break;
         default: return fail(LC_EINVAL, "unknown buffer id %d", what);
     }
     if (!src) return fail(LC_EINVAL, "buffer %d is not produced by this pipeline's configuration", what);
     if (bytes < need) return fail(LC_ECAP, "destination holds %zu bytes, %zu needed", bytes, need);
-    HIP_TRY(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host_dst, src + off, need, hipMemcpyDeviceToHost));
     return LC_OK;
 }
 
@@ -381,15 +451,16 @@ int lc_pipe_read_points(lc_pipe *pipe, int slot, int frame, uint32_t *xy, int ca
     if (!(pipe->p.want_accumulator || pipe->p.want_segments || pipe->p.want_points))
         return fail(LC_EINVAL, "this pipeline's configuration does not produce the point list");
     if (frame < 0 || frame >= s->nframes) return fail(LC_EINVAL, "frame %d out of range [0, %d)", frame, s->nframes);
-    Work &w = s->w;
+    Work &w = pipe->banks[s->bank].w;
+    const size_t f = (size_t)s->pos * pipe->p.max_batch + frame;
     int np = 0;
-    HIP_TRY(hipMemcpy(&np, w.npoints.p + frame, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&np, w.npoints.p + f, sizeof(int), hipMemcpyDeviceToHost));
     *n = np;
     if (np > w.nz_cap) return fail(LC_ECAP, "frame %d has %d edge points, the slot keeps %d", frame, np, w.nz_cap);
     if (np > capacity) return fail(LC_ECAP, "frame %d has %d edge points, destination holds %d", frame, np, capacity);
     if (np > 0) {
         if (!xy) return fail(LC_EINVAL, "null destination");
-        HIP_TRY(hipMemcpy(xy, w.nz.p + (size_t)frame * w.nz_cap, sizeof(uint32_t) * np, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(xy, w.nz.p + f * w.nz_cap, sizeof(uint32_t) * np, hipMemcpyDeviceToHost));
     }
     return LC_OK;
 }
@@ -399,7 +470,9 @@ int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms) {
     int rc;
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!ms) return fail(LC_EINVAL, "null output");
-    if (s->busy || !s->timed) return fail(LC_EINVAL, "slot %d has no complete timing", slot);
+    if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
+    if (!s->timed) return fail(LC_EINVAL, "slot %d: the stage times of its last batch were not recorded (lc_pipe_set_timing)", slot);
+    Bank &bk = pipe->banks[s->bank];
     int a, b;
     switch (stage) {
         case LC_STAGE_UPLOAD: a = EV_START; b = EV_UPLOADED; break;
@@ -410,13 +483,29 @@ int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms) {
             a = EV_POINTS; b = EV_VOTE;
             break;
         case LC_STAGE_LINES: a = EV_LSTART; b = EV_LINES; break;
-        case LC_STAGE_TOTAL: a = EV_START; b = s->end_ev; break;
+        case LC_STAGE_TOTAL: a = EV_START; b = bk.zero_copy ? EV_LINES : EV_END; break;
         case LC_STAGE_FRONT: a = EV_ESTART; b = EV_FRONT; break;
         case LC_STAGE_HYST: a = EV_FRONT; b = EV_HYST; break;
         case LC_STAGE_FINAL: a = EV_HYST; b = EV_EDGE; break;
         default: return fail(LC_EINVAL, "unknown stage %d", stage);
     }
-    HIP_TRY(hipEventElapsedTime(ms, s->ev[a], s->ev[b]));
+    // (the events are those of the bank's latest launch: with several slots to a bank, of the launch that covered them all)
+    HIP_TRY(hipEventElapsedTime(ms, bk.ev[a], bk.ev[b]));
+    return LC_OK;
+}
+
+int lc_pipe_event_times(lc_pipe *pipe, int slot, float *ms12) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!ms12) return fail(LC_EINVAL, "null output");
+    if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight", slot);
+    if (!s->timed || !pipe->ev_base) return fail(LC_EINVAL, "slot %d: the events of its last batch were not recorded (lc_pipe_set_timing)", slot);
+    for (int k = 0; k < 12; k++) {
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, pipe->ev_base, pipe->banks[s->bank].ev[k]) != hipSuccess) { ms = -1.f; (void)hipGetLastError(); }
+        ms12[k] = ms;
+    }
     return LC_OK;
 }
 
@@ -442,11 +531,8 @@ int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_
     if (frames_redone) {
         *frames_redone = 0;
         if (pipe->nlevels > 0 && s->level >= pipe->nlevels) *frames_redone = s->nframes;     // classified in full from the start
-        else if (pipe->nlevels > 0 && s->nframes > 0) {
-            std::vector<int> redo(s->nframes);
-            HIP_TRY(hipMemcpy(redo.data(), s->w.redo.p, sizeof(int) * s->nframes, hipMemcpyDeviceToHost));
-            for (int v : redo) *frames_redone += v != 0;
-        }
+        else if (pipe->nlevels > 0)
+            for (int i = 0; i < s->nframes; i++) *frames_redone += (s->h_rounds[i] >> 30) & 1;
     }
     return LC_OK;
 }
@@ -459,7 +545,7 @@ int lc_pipe_shared_queues(lc_pipe *pipe, int *count) {
 
 int lc_pipe_layout(lc_pipe *pipe, int *group_size, int *lines_streams, int *roi_levels) {
     if (!pipe) return fail(LC_EINVAL, "null pipeline");
-    if (group_size) *group_size = pipe->group_size;
+    if (group_size) *group_size = pipe->parts;
     if (lines_streams) *lines_streams = pipe->p.want_segments ? 1 + (int)pipe->st_lines_more.size() : 0;
     if (roi_levels) *roi_levels = pipe->nlevels;
     return LC_OK;
@@ -472,8 +558,7 @@ int lc_pipe_upload(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes
     if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "upload: bad frames argument");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
     if ((rc = upload_stream(pipe))) return rc;
-    HIP_TRY(hipMemcpyAsync(pipe->resizes ? s->w.src_in.p : s->w.bgr.p, host_bgr, (size_t)nframes * pipe->src_frame_bytes,
-                           hipMemcpyHostToDevice, pipe->st_up));
+    HIP_TRY(hipMemcpyAsync(own_input(pipe, *s), host_bgr, (size_t)nframes * pipe->src_frame_bytes, hipMemcpyHostToDevice, pipe->st_up));
     HIP_TRY(hipStreamSynchronize(pipe->st_up));
     return LC_OK;
 }
@@ -483,7 +568,7 @@ int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr) {
     int rc;
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!dev_ptr) return fail(LC_EINVAL, "null output");
-    *dev_ptr = pipe->resizes ? s->w.src_in.p : s->w.bgr.p;
+    *dev_ptr = own_input(pipe, *s);
     return LC_OK;
 }
 

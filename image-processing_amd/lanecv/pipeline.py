@@ -102,9 +102,10 @@ class Recipe:
 
 class LanePipeline:
     def __init__(self, width, height, recipe, max_batch=32, nslots=2, seg_capacity=128,
-                 keep_intermediates=False, device=None, src_size=None):
+                 keep_intermediates=False, device=None, src_size=None, timing=False):
         """src_size = (width, height) of the submitted frames when they differ from the pipeline's size: the
-        pipeline then starts with ``cv2.resize(frame, (width, height))`` (`F1_vo_Lane_Tracking.py:185`)."""
+        pipeline then starts with ``cv2.resize(frame, (width, height))`` (`F1_vo_Lane_Tracking.py:185`).
+        timing: record the HIP events `stage_ms` reads (off by default: they are extra packets on every batch)."""
         import lanecv as cv2
         self.w, self.h, self.recipe = int(width), int(height), recipe
         self.sw, self.sh = (int(src_size[0]), int(src_size[1])) if src_size is not None else (self.w, self.h)
@@ -141,6 +142,8 @@ class LanePipeline:
         self._ctx = _abi.context(device)
         _abi.check(_abi.lib().lc_pipe_create(self._ctx, C.byref(p), C.byref(self._h)))
         self._n = [0] * self.nslots
+        if timing:
+            self.set_timing(True)
         self._keepalive = [None] * self.nslots     # host frames of the batch in flight, per slot (the copy is asynchronous)
         self._pinned = []                          # page-locked blocks handed out by pinned_frames
         na, nr = C.c_int(), C.c_int()
@@ -279,6 +282,17 @@ class LanePipeline:
         n = C.c_int()
         _abi.check(_abi.lib().lc_pipe_shared_queues(self._h, C.byref(n)))
         return n.value
+
+    def set_timing(self, on):
+        """Batches submitted from now on record (or no longer record) the events `stage_ms` reads."""
+        _abi.check(_abi.lib().lc_pipe_set_timing(self._h, int(bool(on))))
+
+    def event_times(self, slot):
+        """ms since the pipeline's creation at which the slot's last batch passed each of its twelve events
+        (negative: not recorded); needs timing."""
+        out = (C.c_float * 12)()
+        _abi.check(_abi.lib().lc_pipe_event_times(self._h, slot, out))
+        return list(out)
 
     def layout(self):
         """(slots per HoughLinesP launch, HoughLinesP streams, levels of the ROI scheme)."""

@@ -238,7 +238,8 @@ int lc_pipe_destroy(lc_pipe *pipe);
  * slot on its stream and enqueues the whole pipeline behind the copy. */
 int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes);
 /* Same, but the frames already sit in device memory (no copy is made; the
- * buffer must stay valid until lc_pipe_wait returns). */
+ * buffer must stay valid and unchanged until lc_pipe_wait returns: a frame the pipeline's short cuts cannot settle
+ * is read a second time from there, during the wait). */
 int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nframes);
 /* Blocks until the slot is done, then copies the segments out:
  * seg_xyxy [nframes][seg_capacity][4] int32, seg_count [nframes] int32 (either may be NULL).
@@ -251,7 +252,16 @@ int lc_pipe_read(lc_pipe *pipe, int slot, int what, void *host_dst, size_t bytes
  * frame's HoughLinesP fallback could have permuted the list: it is exact whenever the status is clean).
  * *n receives the count; LC_ECAP if it exceeds `capacity`. */
 int lc_pipe_read_points(lc_pipe *pipe, int slot, int frame, uint32_t *xy, int capacity, int *n);
+/* Stage times of the slot's last batch, from HIP events on the streams the stages ran on.  The events are only
+ * recorded for batches submitted after lc_pipe_set_timing(pipe, 1) (a dozen more packets per batch on the pipeline's
+ * streams: worth leaving off for small batches, whose rate the host's launch calls bound); LC_EINVAL otherwise.
+ * Diagnostics with no counterpart in the reference. */
 int lc_pipe_stage_ms(lc_pipe *pipe, int slot, int stage, float *ms);
+int lc_pipe_set_timing(lc_pipe *pipe, int on);
+/* Diagnostics: when the twelve events of the slot's last batch fired, in milliseconds since the pipeline was created
+ * (START UPLOADED FRONT HYST EDGE POINTS VOTE LINES END ESTART LSTART VSTART; a negative value = not recorded for that
+ * batch).  Needs lc_pipe_set_timing(pipe, 1). */
+int lc_pipe_event_times(lc_pipe *pipe, int slot, float *ms12);
 /* Device pointer of a slot's own input buffer (for callers that fill it on the device). */
 int lc_pipe_input_device_ptr(lc_pipe *pipe, int slot, void **dev_ptr);
 /* Hysteresis diagnostics of the slot's last batch: rounds until the fixed point (the first

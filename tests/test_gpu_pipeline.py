@@ -78,7 +78,7 @@ def test_slots_overlap_and_reuse(oracle, nslots):
     from lanecv.pipeline import LanePipeline, Recipe
     w, h = 960, 540
     rec = Recipe.north_star(w, h)
-    pipe = LanePipeline(w, h, rec, max_batch=8, nslots=nslots)
+    pipe = LanePipeline(w, h, rec, max_batch=8, nslots=nslots, timing=True)
     pinned = [pipe.pinned_frames(8) for _ in range(nslots)]
     batches = []
     for b in range(2 * nslots):

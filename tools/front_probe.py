@@ -13,7 +13,7 @@ with mp.get_context("fork").Pool(16) as pool:
     frames = np.stack(pool.map(gen, range(batch), chunksize=4))
 for canny in [(100, 200), (100000, 200000)]:
     rec = dataclasses.replace(Recipe.north_star(1920, 1080), canny=canny, segments=False, accumulator=False)
-    pipe = LanePipeline(1920, 1080, rec, max_batch=batch, nslots=1, seg_capacity=128, device=0)
+    pipe = LanePipeline(1920, 1080, rec, max_batch=batch, nslots=1, seg_capacity=128, device=0, timing=True)
     ptr = pipe.upload(0, frames)
     ts = []
     for i in range(int(os.environ.get("FRONT_PROBE_ITERS", "6"))):

@@ -8,7 +8,7 @@ from lanecv.pipeline import LanePipeline, Recipe
 w,h=1920,1080
 rec=Recipe.north_star(w,h)
 B=int(sys.argv[1]) if len(sys.argv)>1 else 32
-pipe=LanePipeline(w,h,rec,max_batch=B,nslots=1)
+pipe=LanePipeline(w,h,rec,max_batch=B,nslots=1, timing=True)
 fr=np.stack([synth.synth_road(w,h,100,t) for t in range(B)])
 for it in range(1):
     pipe.submit(0, fr); pipe.collect(0)

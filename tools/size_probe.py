@@ -12,7 +12,7 @@ def gen(t): return synth.synth_road(w, h, 100, t)
 with mp.get_context("fork").Pool(16) as pool:
     frames = np.stack(pool.map(gen, range(batch), chunksize=2))
 rec = Recipe.north_star(w, h)
-pipe = LanePipeline(w, h, rec, max_batch=batch, nslots=nslots, seg_capacity=256, device=0)
+pipe = LanePipeline(w, h, rec, max_batch=batch, nslots=nslots, seg_capacity=256, device=0, timing=True)
 ptr = pipe.upload(0, frames)
 for s in range(nslots):
     pipe.submit_device(s, ptr, batch); pipe.wait(s)
