@@ -72,12 +72,11 @@ struct lc_pipe {
     //             vote kernel of accumulator-only recipes); with a single slot it is st_edge itself.
     //   st_lines  HoughLinesP and the copy of the batch's results.
     hipStream_t st_up = nullptr, st_edge = nullptr, st_post = nullptr, st_lines = nullptr;
-    // More HoughLinesP streams for small batches: the kernel is one sequential workgroup per frame that takes a CU
-    // for itself, so a batch of 32 frames leaves 7/8 of the chip to whatever may run beside it -- and on a single
-    // stream that is never another batch's HoughLinesP.  Batches take the streams in turn: CUs / max_batch of them,
-    // at most three and one fewer than there are slots (720p x 32: 71 k frames/s with one stream, 124 k with two
-    // of three slots, 146 k with three of six; four were slower again).  One stream when the batch fills the CUs (a
-    // second one gained nothing there); LANECV_LINES_STREAMS overrides the count.
+    // More HoughLinesP streams: the kernel is one sequential workgroup per frame, so a launch over fewer frames than
+    // the GPU has room for leaves the rest to whatever may run beside it -- and on a single stream that is never
+    // another bank's HoughLinesP.  Launches take the streams in turn: as many as launches fit the GPU side by side
+    // ((two frames per CU ? 2 : 1) * CUs / frames of a bank), at most three and no more than there are banks.
+    // LANECV_LINES_STREAMS overrides the count.
     std::vector<hipStream_t> st_lines_more;
     unsigned lines_turn = 0;
     // The streaming front kernel's unit height (fixed for the pipeline's largest batch: its change tracking is per unit)

@@ -275,7 +275,7 @@ int setup_streams(lc_pipe *pp) {
         if (own_lines) {
             int want = 1;
             if (pp->cu_count > 0)
-                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * pp->cu_count / pp->bank_frames, (int)pp->banks.size() - 1), 3));
+                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * pp->cu_count / pp->bank_frames, (int)pp->banks.size()), 3));
             const char *ns = getenv("LANECV_LINES_STREAMS");
             if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
             for (int k = 1; k < want; k++) {

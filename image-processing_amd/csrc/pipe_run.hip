@@ -164,10 +164,19 @@ int launch_bank(lc_pipe *pp, int bi) {
     if (ps != es || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_FRONT], es));
     if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, bk.ev[EV_FRONT], 0));
     // Hysteresis; with an ROI level active the frame's workgroup then proves that the units classified settle the ROI's
-    // edges, or flags the frame (rare): lc_pipe_wait classifies flagged frames again in full and redoes what follows.
+    // edges, or flags the frame (rare).  Flagged frames: all units again, and their hysteresis -- two launches that
+    // leave at once for the other frames, which is nearly always all of them.  (What the full passes leave in the plane
+    // rows of units the level does not classify is cleared before the bank's next launch: lc_pipe_wait sees the flag.)
     const lc_pipe::SkipLevel *SL = skipping ? &pp->levels[L.level] : nullptr;
     launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status, nullptr, SL ? SL->ring_words.p : nullptr,
                       SL ? SL->n_ring_words : 0, SL ? SL->ring_code.p : nullptr, w.redo.p, &L.fs);
+    if (skipping) {
+        const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
+        launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
+                     nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize,
+                     pp->front_rows, &again, &L.fs, L.src);
+        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs);
+    }
     stamp(pp, bk, EV_HYST, ps);
     enqueue_post(pp, bk, L, ps);
     hipStream_t ls = next_lines_stream(pp);
@@ -269,35 +278,6 @@ int wait_event(lc_pipe *pipe, int slot, hipEvent_t ev) {
     }
 }
 
-// Frames of slot s whose edges the units near the ROI did not settle (flagged by the hysteresis kernel; the host has
-// just seen the slot's status word): all units of those frames once more, their hysteresis, and then everything behind
-// it for the slot's whole batch -- finalize rewrites what changed, the point lists and HoughLinesP are made again.  On
-// the post stream, in order behind whatever else is queued there.  The slot's input must still be where it was
-// submitted.
-void enqueue_repair(lc_pipe *pp, Slot &s) {
-    Bank &bk = pp->banks[s.bank];
-    Work &w = bk.w;
-    const lc_pipe_params &p = pp->p;
-    Slot *first = &pp->slots[(size_t)s.bank * pp->parts];
-    Launch L;
-    L.fs.per_part = p.max_batch;
-    for (int j = 0; j < bk.parts; j++) L.src[j] = first[j].input;
-    L.fs.count[s.pos] = s.nframes;
-    L.nframes = s.pos * p.max_batch + s.nframes;
-    L.level = pp->nlevels;
-    hipStream_t ps = pp->st_post;
-    const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
-    const size_t src_bytes = (size_t)L.nframes * (pp->resizes && !pp->fused_dec3() ? 3 * w.npix : pp->src_frame_bytes);
-    launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, L.nframes, pp->low, pp->high,
-                 w.planeS.p, w.planeW.p, w.wake.p, nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p,
-                 w.rowflags.p, pp->fused_dec3(), pp->front_rows, &again, &L.fs, L.src);
-    launch_hysteresis(w.g, L.nframes, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs);
-    enqueue_post(pp, bk, L, ps);
-    enqueue_lines(pp, bk, first, L, ps);
-    // the full passes stored plane rows in units the slot's level does not classify: cleared before the bank's next launch
-    bk.planes_level = pp->nlevels;
-}
-
 }  // namespace
 
 namespace lanecv {
@@ -345,11 +325,11 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     const lc_pipe_params &p = pipe->p;
     if (s->pending && (rc = launch_bank(pipe, s->bank))) return rc;      // its bank is not full: what is there goes now
     if ((rc = wait_event(pipe, slot, s->done))) return rc;
-    // The common case ends here.  Two rare ones were left out of the submit so that it queues nothing that is not needed,
-    // and are made up for now that the host can see the batch's status words:
     if (s->level < pipe->nlevels && s->h_status[3]) {
-        // frames the ROI scheme could not settle from the units near the ROI: classified in full, the batch's later
-        // stages made again
+        // Frames the ROI scheme could not settle from the units near the ROI were classified again in full.  Their full
+        // passes stored plane rows in units the level does not classify: cleared before the bank's next launch.  And a
+        // batch with many of them moves the pipeline a level out.
+        pipe->banks[s->bank].planes_level = pipe->nlevels;
         int redone = 0;
         for (int i = 0; i < s->nframes; i++) redone += (s->h_rounds[i] >> 30) & 1;
         const char *ob = getenv("LANECV_SKIP_OFF_BATCHES");         // diagnostics / tests; 0 = never move a level out
@@ -358,12 +338,11 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
             pipe->level = s->level + 1;
             pipe->level_hold = off_batches;
         }
-        enqueue_repair(pipe, *s);
-        HIP_TRY(hipGetLastError());
-        if ((rc = wait_event(pipe, slot, s->done))) return rc;
     }
     if (p.want_segments && s->fast_lines && s->h_status[4]) {
-        // frames with more edge points than the LDS-resident HoughLinesP kernel takes: the general kernel, for them
+        // Frames with more edge points than the LDS-resident HoughLinesP kernel takes (it raised a status word of the
+        // slot): the general kernel, for them.  Left out of the submit, where nearly always it would have been a packet
+        // on the HoughLinesP stream that finds nothing to do.
         Work &w = pipe->banks[s->bank].w;
         const bool vote_fused = vote_is_fused(pipe);
         hipStream_t ps = pipe->st_post;

@@ -238,8 +238,8 @@ int lc_pipe_destroy(lc_pipe *pipe);
  * slot on its stream and enqueues the whole pipeline behind the copy. */
 int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes);
 /* Same, but the frames already sit in device memory (no copy is made; the
- * buffer must stay valid and unchanged until lc_pipe_wait returns: a frame the pipeline's short cuts cannot settle
- * is read a second time from there, during the wait). */
+ * buffer must stay valid and unchanged until lc_pipe_wait on the slot returns: the kernels run some time after
+ * this call, and a frame the pipeline's short cuts cannot settle is read a second time). */
 int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nframes);
 /* Blocks until the slot is done, then copies the segments out:
  * seg_xyxy [nframes][seg_capacity][4] int32, seg_count [nframes] int32 (either may be NULL).

@@ -264,10 +264,30 @@ def test_bench_launch_shape_parity(oracle):
     with ThreadPoolExecutor(8) as ex:
         want = list(ex.map(lambda f: _oracle_frame(oracle, f, rec, pipe.roi), distinct))
     rotations = [0, 5, 10, 3]
+    # One of the four device batches also holds frames the ROI scheme cannot settle from the units near the ROI -- faint
+    # vertical edges made edges only by their strong upper ends far above it, and a frame of noise (which also has more
+    # edge points than the LDS-resident HoughLinesP kernel takes): the second pass over flagged frames and the general
+    # HoughLinesP kernel at the benchmark's launch shape, between clean batches in the same slots.
+    def faint_edge(x, ytop, flip=False):
+        g = np.full((h, w), 60, np.int32)
+        g[:ytop, x:] += 120
+        g[ytop:, x:] += 60
+        f = np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+        return f[:, ::-1].copy() if flip else f
+
+    special = {7: faint_edge(w // 2 + 60, 150), 100: faint_edge(w // 2 + 200, 40, flip=True), 200: faint_edge(w // 2 + 90, 300),
+               255: synth.adversarial_frames(w, h)["noise"]}
+    with ThreadPoolExecutor(4) as ex:
+        want_special = dict(zip(special, ex.map(lambda f: _oracle_frame(oracle, f, rec, pipe.roi), special.values())))
+    assert np.count_nonzero(want_special[255]["masked"]) > 16383
+    dirty = 2                                       # the device batch that holds them
     dev = []
     try:
-        for rot in rotations:
+        for b, rot in enumerate(rotations):
             host = np.stack([distinct[(i + rot) % ndistinct] for i in range(B)])
+            if b == dirty:
+                for i, f in special.items():
+                    host[i] = f
             d = hiprt.DeviceBuffer(host.nbytes)
             d.upload(host)
             dev.append(d)
@@ -277,11 +297,14 @@ def test_bench_launch_shape_parity(oracle):
             seg, cnt = pipe.wait(slot)
             masked = pipe.read(slot, _abi.BUF_MASKED)
             acc = pipe.read(slot, _abi.BUF_ACC)
-            rot = rotations[k % len(rotations)]
+            b = k % len(rotations)
+            rot = rotations[b]
+            assert pipe.roi_skip(slot)[2] == (len(special) if b == dirty else 0), (k, pipe.roi_skip(slot))
             for i in range(B):
-                r = want[(i + rot) % ndistinct]
+                r = want_special[i] if (b == dirty and i in special) else want[(i + rot) % ndistinct]
                 assert cnt[i] == len(r["segments"]), (k, i)
-                assert np.array_equal(seg[i, :cnt[i]], r["segments"]), (k, i)
+                m = min(cnt[i], seg.shape[1])
+                assert np.array_equal(seg[i, :m], r["segments"][:m]), (k, i)
                 assert np.array_equal(masked[i], r["masked"]), (k, i)
                 assert np.array_equal(acc[i], r["acc"]), (k, i)
 
