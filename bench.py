@@ -52,7 +52,7 @@ def make_frames(seed, n, workers):
 def pmc_traffic(batch):
     """HBM bytes per k_front_stream launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
     WRITE_SIZE runs, FETCH_SIZE doubled as gfx950 needs); None when the launch shape differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "round2_pmc_edge_stage.json")
+    path = os.path.join(ROOT, "profiles", "round3_pmc_edge_stage.json")
     if batch != 256 or not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -94,22 +94,139 @@ def vote_rates(dev_ptr, batch, device):
                     "take stretches of the sorted point list that lie n/64 points apart, so that they rarely meet in a bin)"}
 
 
-def cpu_baseline(frames, rec, roi, threads):
-    """The CPU oracle (a scalar C port of the OpenCV arithmetic), frame-parallel over `threads` host threads."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def probe_cv2():
+    """What `import cv2` did on this host, as observed: the reference's arithmetic lives in that module."""
+    try:
+        import cv2
+    except Exception as e:          # ModuleNotFoundError here; anything else is worth reading too
+        return None, {"cv2": "absent", "import_error": "%s: %s" % (type(e).__name__, e)}
+    info = {"cv2": cv2.__version__, "threads": cv2.getNumThreads()}
+    try:
+        build = cv2.getBuildInformation()
+        info["build_lines"] = [ln.strip() for ln in build.splitlines()
+                               if any(k in ln for k in ("Version control", "CPU/HW features", "Baseline", "Intel IPP", "Parallel framework"))][:8]
+    except Exception:
+        pass
+    try:
+        if hasattr(cv2, "ipp"):
+            cv2.ipp.setUseIPP(False)          # the generic code path is the contract
+            info["ipp"] = "switched off"
+    except Exception:
+        pass
+    return cv2, info
+
+
+def _median_rate(fn, frames, repeats):
+    """frames/s of fn over `frames`: a warm-up over a tenth of them, then the median of `repeats` timed passes."""
+    import numpy as np
+    fn(frames[:max(1, len(frames) // 10)])
+    rates = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        fn(frames)
+        rates.append(len(frames) / (time.perf_counter() - t0))
+    return float(np.median(rates)), [round(r, 2) for r in rates]
+
+
+def cpu_baseline(frames, rec, roi_vertices, roi, threads, budget_s=24.0):
+    """The CPU side of the same recipe on the same frames, on this host: the reference's own cv2 call sequence
+    (`Simple Lane Detection with OpenCV_2(images).py:69-92` with the 5x5 blur of `F1_vo_Lane_Tracking.py:97` in front of
+    Canny, per frame, the ROI mask rebuilt every frame as the scripts do) when cv2 can be imported, and in any case the
+    oracle -- a scalar C port of the OpenCV arithmetic -- frame-parallel over `threads` host threads.  Warm-up over a
+    tenth of the sample, median of five timed passes, stage by stage for one thread as well."""
+    import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import lane_oracle as lo
     lo.lib()
+    cv2, cv2_info = probe_cv2()
 
-    def one(f):
+    def oracle_frame(f):
         lo.lane_frame(f, rec.color_code, rec.blur, rec.canny[0], rec.canny[1], roi, rec.rho, rec.theta,
                       rec.threshold, rec.min_line_length, rec.max_line_gap, want_acc=True, want_segments=True)
 
-    one(frames[0])
+    # sample size: about budget_s seconds of CPU work in all (six passes over the sample on `threads` threads)
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(one, frames))
-    dt = time.perf_counter() - t0
-    return len(frames) / dt
+    oracle_frame(frames[0])
+    one = time.perf_counter() - t0
+    n = int(max(threads, min(len(frames), budget_s * threads / (6.6 * one))))
+    sample = frames[:n]
+
+    def oracle_all(fr):
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(oracle_frame, fr))
+
+    rate, rates = _median_rate(oracle_all, sample, 5)
+    # stage by stage, one thread, a few frames: where the port's time goes
+    k = min(4, len(sample))
+    stage = {"gray": 0.0, "blur": 0.0, "canny": 0.0, "roi_and": 0.0, "accumulator": 0.0, "hough_lines_p": 0.0}
+    for f in sample[:k]:
+        t = [time.perf_counter()]
+        g = lo.cvt_gray(f, rec.color_code); t.append(time.perf_counter())
+        if rec.blur:
+            g = lo.gaussian5(g)
+        t.append(time.perf_counter())
+        e = lo.canny(g, rec.canny[0], rec.canny[1]); t.append(time.perf_counter())
+        m = np.zeros_like(e)
+        lo.fill_poly(m, roi_vertices, 255)
+        e = lo.bitwise_and(e, m); t.append(time.perf_counter())
+        lo.hough_accum(e, rec.rho, rec.theta); t.append(time.perf_counter())
+        lo.hough_lines_p(e, rec.rho, rec.theta, rec.threshold, rec.min_line_length, rec.max_line_gap); t.append(time.perf_counter())
+        for name, dt in zip(stage, np.diff(t)):
+            stage[name] += dt * 1e3 / k
+    out = {"value": round(rate, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": "%d of the same 1080p frames through the same recipe with the scalar C oracle, frame-parallel over %d threads; "
+                     "warm-up over a tenth of them, median of 5 passes" % (len(sample), threads),
+           "passes_fps": rates, "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+           "stage_ms_per_frame_one_thread": {k_: round(v, 3) for k_, v in stage.items()}}
+    out.update(cv2_info)
+    if cv2 is not None:
+        # the literal reference sequence through cv2, per frame, (i) one cv2 thread, (ii) cv2's own threads, one process
+        def cv2_frame(f):
+            g = cv2.cvtColor(f, cv2.COLOR_BGR2GRAY if rec.color_code == 6 else cv2.COLOR_RGB2GRAY)
+            if rec.blur:
+                g = cv2.GaussianBlur(g, (5, 5), 0)
+            e = cv2.Canny(g, rec.canny[0], rec.canny[1])
+            m = np.zeros_like(e)
+            cv2.fillPoly(m, roi_vertices, 255)
+            e = cv2.bitwise_and(e, m)
+            cv2.HoughLinesP(e, rec.rho, rec.theta, rec.threshold, lines=np.array([]), minLineLength=rec.min_line_length,
+                            maxLineGap=rec.max_line_gap)
+
+        def cv2_all(fr):
+            for f in fr:
+                cv2_frame(f)
+
+        nthreads = cv2.getNumThreads()
+        cv2.setNumThreads(1)
+        r1, _ = _median_rate(cv2_all, sample[:max(8, n // threads)], 5)
+        cv2.setNumThreads(nthreads)
+        rn, _ = _median_rate(cv2_all, sample[:max(8, n // 4)], 5)
+
+        def cv2_pool(fr):
+            with ThreadPoolExecutor(threads) as ex:      # cv2 releases the GIL inside its calls
+                list(ex.map(cv2_frame, fr))
+
+        cv2.setNumThreads(1)
+        rp, _ = _median_rate(cv2_pool, sample, 5)
+        cv2.setNumThreads(nthreads)
+        out["cv2_fps"] = {"one_thread": round(r1, 2), "cv2_threads": round(rn, 2), "frame_parallel_%d_threads" % threads: round(rp, 2)}
+        out["value"] = round(max(rn, rp), 2)
+        out["kind"] = "reference"
+        out["port_fps"] = round(rate, 2)
+        out["sample"] = out["sample"].replace("with the scalar C oracle", "through cv2 (value: the better of cv2's own threads and "
+                                              "frame-parallel cv2) and with the scalar C oracle (port_fps)")
+    return out
 
 
 def main():
@@ -372,6 +489,8 @@ def main():
             for s in inflight:
                 pipe.wait(s)
             sfps = ssteps * batch / (time.perf_counter() - t1)
+            rows_from = pipe.rows_uploaded((ssteps - 1) % args.slots)      # with an ROI only the rows the kernels read are copied
+            sent_bytes = 3 * W * (H - rows_from)
             src = torch.from_numpy(pinned[0].reshape(-1))           # the same pinned block, copied by torch alone
             dst = torch.empty(src.numel(), dtype=torch.uint8, device="cuda")
             best = 0.0
@@ -382,19 +501,19 @@ def main():
                 torch.cuda.synchronize()
                 best = max(best, src.numel() / (time.perf_counter() - t2) / 1e9)
             out["streaming_fps_pcie_inclusive"] = round(sfps, 1)
-            out["streaming_roofline"] = {"bound": "pcie", "achieved": round(sfps * frame_bytes / 1e9, 2), "peak": round(best, 2),
-                                         "unit": "GB/s", "frac": round(sfps * frame_bytes / 1e9 / best, 4),
-                                         "note": "peak = host-to-device rate of one pinned %d-frame batch copied alone, measured "
-                                                 "in this run" % batch}
+            out["streaming_roofline"] = {"bound": "pcie", "achieved": round(sfps * sent_bytes / 1e9, 2), "peak": round(best, 2),
+                                         "unit": "GB/s", "frac": round(sfps * sent_bytes / 1e9 / best, 4),
+                                         "bytes_sent_per_frame": sent_bytes, "first_row_sent": rows_from,
+                                         "whole_frame_equivalent_GBs": round(sfps * frame_bytes / 1e9, 2),
+                                         "note": "achieved = bytes actually copied (rows %d..%d of every frame: the rows the "
+                                                 "kernels read with the triangle ROI; a frame that needs the rest after all is "
+                                                 "fetched when its slot is waited for) x frames/s; peak = host-to-device rate of "
+                                                 "one pinned %d-frame batch copied alone, measured in this run"
+                                                 % (rows_from, H - 1, batch)}
             del dst
 
         if world == 1 and not args.no_cpu_baseline:
-            sample = frames[:min(len(frames), 128)]
-            v = cpu_baseline(sample, rec, pipe.roi, host_threads)
-            out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": host_threads, "kind": "port",
-                                   "sample": "%d of the same 1080p frames through the same recipe with the scalar C oracle "
-                                             "(cv2 is not installed on this image), frame-parallel over %d threads"
-                                             % (len(sample), host_threads)}
+            out["cpu_baseline"] = cpu_baseline(frames[:min(len(frames), 256)], rec, rec.roi_vertices, pipe.roi, host_threads)
         print(json.dumps(out), flush=True)
 
     pipe.close()

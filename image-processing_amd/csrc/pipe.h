@@ -14,6 +14,9 @@ struct Slot {
     int nframes = 0;
     const uint8_t *input = nullptr;   // device pointer of the submitted frames (inside the bank's own input buffer for host submits)
     bool from_host = false;
+    const uint8_t *host_src = nullptr;  // host submits: where the frames came from (stays valid until the slot has been waited for)
+    int rows_from = 0;                // host submits: the first row of every frame that has been uploaded so far
+    bool eager_redo = true;           // its launch classified flagged frames again itself (it could: they were there in full)
     bool busy = false;                // submitted and not yet waited for
     bool pending = false;             // submitted, but the bank's kernels for it are not queued yet
     bool timed = false;               // the launch that covers it recorded the stage events

@@ -92,6 +92,29 @@ void enqueue_lines(lc_pipe *pp, Bank &bk, Slot *first, const Launch &L, hipStrea
     }
 }
 
+// First row of a frame the kernels of a launch at `level` read: a few rows above the first row classified (the front
+// kernel warms its blur and Sobel windows up on them); 0 at the full level.
+int first_row_read(const lc_pipe *pp, int level) {
+    if (level >= pp->nlevels || pp->resizes) return 0;
+    const int r0 = pp->row_split - 8;
+    return r0 < 16 ? 0 : r0;
+}
+
+// copies rows [r0, r1) of each of the slot's n frames from the host buffer it was submitted from, on the upload stream
+int upload_rows(lc_pipe *pipe, Slot &s, int r0, int r1) {
+    if (r1 <= r0) return LC_OK;
+    const size_t row_bytes = (size_t)3 * pipe->src_w, off = (size_t)r0 * row_bytes, bytes = (size_t)(r1 - r0) * row_bytes;
+    uint8_t *dst = const_cast<uint8_t *>(s.input);
+    if (r0 == 0 && r1 == pipe->src_h) {
+        HIP_TRY(hipMemcpyAsync(dst, s.host_src, (size_t)s.nframes * pipe->src_frame_bytes, hipMemcpyHostToDevice, pipe->st_up));
+        return LC_OK;
+    }
+    // (one row of the 2-D copy = the rows [r0, r1) of one frame, which lie back to back; its pitch = a whole frame)
+    HIP_TRY(hipMemcpy2DAsync(dst + off, pipe->src_frame_bytes, s.host_src + off, pipe->src_frame_bytes, bytes, s.nframes,
+                             hipMemcpyHostToDevice, pipe->st_up));
+    return LC_OK;
+}
+
 hipStream_t next_lines_stream(lc_pipe *pp) {
     if (!pp->p.want_segments) return pp->st_post;
     const unsigned turn = pp->lines_turn++ % (unsigned)(1 + pp->st_lines_more.size());
@@ -119,6 +142,28 @@ int launch_bank(lc_pipe *pp, int bi) {
     if (L.nframes == 0) return LC_OK;
     const int n = L.nframes;
     hipStream_t es = pp->st_edge, ps = pp->st_post;
+    if (pp->level > 0 && pp->nlevels > 0) {
+        if (pp->level_hold > 0) pp->level_hold--;
+        else { pp->level--; pp->level_hold = 0; }     // try one level in again
+    }
+    L.level = pp->nlevels > 0 ? pp->level : 0;
+    // (no clearing of plane rows beside a launch that may still be reading them: stay at the looser level this once)
+    if (older && L.level < bk.planes_level) L.level = std::min(bk.planes_level, pp->nlevels);
+    // Frames submitted from host memory were uploaded from the first row the level expected at the time reads; if the
+    // launch's level reads more, the rows above follow now.  Frames that are not there in full cannot be classified
+    // again in the stream: lc_pipe_wait does that for the frames flagged, after fetching the rest of them.
+    bool eager = true;
+    for (int j = 0; j < bk.parts; j++) {
+        Slot &s = first[j];
+        if (!s.pending || !s.from_host) continue;
+        const int need_from = first_row_read(pp, L.level);
+        if (s.rows_from > need_from) {
+            int rc;
+            if ((rc = upload_rows(pp, s, need_from, s.rows_from))) return rc;
+            s.rows_from = need_from;
+        }
+        eager = eager && s.rows_from == 0;
+    }
     if (from_host) {
         HIP_TRY(hipEventRecord(bk.ev[EV_UPLOADED], pp->st_up));     // behind the copies of every pending slot
         HIP_TRY(hipStreamWaitEvent(es, bk.ev[EV_UPLOADED], 0));
@@ -133,13 +178,6 @@ int launch_bank(lc_pipe *pp, int bi) {
         launch_resize_linear(L.src[0], pp->src_w, pp->src_h, 3, n, w.bgr.p, w.g.W, w.g.H, pp->resize_tab.p, pp->resize_area2, es, pp->resize_dec3);
         L.src[0] = first[0].input = w.bgr.p;
     }
-    if (pp->level > 0 && pp->nlevels > 0) {
-        if (pp->level_hold > 0) pp->level_hold--;
-        else { pp->level--; pp->level_hold = 0; }     // try one level in again
-    }
-    L.level = pp->nlevels > 0 ? pp->level : 0;
-    // (no clearing of plane rows beside a launch that may still be reading them: stay at the looser level this once)
-    if (older && L.level < bk.planes_level) L.level = std::min(bk.planes_level, pp->nlevels);
     const bool skipping = L.level < pp->nlevels;
     const FrontSplit skip = pp->split(L.level, 1, nullptr);
     // (what the tiled kernel may read of a one-slot bank's frames)
@@ -170,7 +208,7 @@ int launch_bank(lc_pipe *pp, int bi) {
     const lc_pipe::SkipLevel *SL = skipping ? &pp->levels[L.level] : nullptr;
     launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status, nullptr, SL ? SL->ring_words.p : nullptr,
                       SL ? SL->n_ring_words : 0, SL ? SL->ring_code.p : nullptr, w.redo.p, &L.fs);
-    if (skipping) {
+    if (skipping && eager) {
         const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
         launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
                      nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize,
@@ -192,6 +230,7 @@ int launch_bank(lc_pipe *pp, int bi) {
         first[j].pending = false;
         first[j].level = L.level;
         first[j].timed = pp->timing;
+        first[j].eager_redo = eager;
     }
     return LC_OK;
 }
@@ -278,6 +317,44 @@ int wait_event(lc_pipe *pipe, int slot, hipEvent_t ev) {
     }
 }
 
+// Frames of slot s whose edges the units near the ROI did not settle, when the launch could not classify them again
+// itself (they were not in device memory in full): the rows that were not uploaded are fetched for the flagged frames
+// from the host buffer the slot was submitted from, then all units of those frames once more, their hysteresis, and
+// everything behind it for the slot's whole batch -- finalize rewrites what changed, the point lists and HoughLinesP
+// are made again.  On the post stream, in order behind whatever else is queued there.
+int enqueue_repair(lc_pipe *pp, Slot &s) {
+    Bank &bk = pp->banks[s.bank];
+    Work &w = bk.w;
+    const lc_pipe_params &p = pp->p;
+    Slot *first = &pp->slots[(size_t)s.bank * pp->parts];
+    hipStream_t ps = pp->st_post;
+    if (s.from_host && s.rows_from > 0) {
+        const size_t bytes = (size_t)s.rows_from * 3 * pp->src_w;
+        for (int i = 0; i < s.nframes; i++)
+            if ((s.h_rounds[i] >> 30) & 1)
+                HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(s.input) + (size_t)i * pp->src_frame_bytes, s.host_src + (size_t)i * pp->src_frame_bytes,
+                                       bytes, hipMemcpyHostToDevice, pp->st_up));
+        HIP_TRY(hipEventRecord(bk.ev[EV_UPLOADED], pp->st_up));
+        HIP_TRY(hipStreamWaitEvent(ps, bk.ev[EV_UPLOADED], 0));
+    }
+    Launch L;
+    L.fs.per_part = p.max_batch;
+    for (int j = 0; j < bk.parts; j++) L.src[j] = first[j].input;
+    L.fs.count[s.pos] = s.nframes;
+    L.nframes = s.pos * p.max_batch + s.nframes;
+    L.level = pp->nlevels;
+    const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
+    const size_t src_bytes = (size_t)L.nframes * (pp->resizes && !pp->fused_dec3() ? 3 * w.npix : pp->src_frame_bytes);
+    launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, L.nframes, pp->low, pp->high,
+                 w.planeS.p, w.planeW.p, w.wake.p, nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p,
+                 w.rowflags.p, pp->fused_dec3(), pp->front_rows, &again, &L.fs, L.src);
+    launch_hysteresis(w.g, L.nframes, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs);
+    enqueue_post(pp, bk, L, ps);
+    enqueue_lines(pp, bk, first, L, ps);
+    HIP_TRY(hipGetLastError());
+    return LC_OK;
+}
+
 }  // namespace
 
 namespace lanecv {
@@ -295,12 +372,17 @@ int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nf
     if (!host_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "submit: bad frames argument");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
     s->nframes = nframes;
-    uint8_t *own = own_input(pipe, *s);
-    s->input = own;
+    s->input = own_input(pipe, *s);
     s->from_host = true;
+    s->host_src = host_bgr;
     if ((rc = upload_stream(pipe))) return rc;
     if (pipe->timing) HIP_TRY(hipEventRecord(pipe->banks[s->bank].ev[EV_START], pipe->st_up));
-    HIP_TRY(hipMemcpyAsync(own, host_bgr, (size_t)nframes * pipe->src_frame_bytes, hipMemcpyHostToDevice, pipe->st_up));
+    // Only the rows the kernels will read: with an ROI level active, those from a little above the first row classified
+    // (the level is the one the pipeline is at now; launch_bank fetches the rest should the launch need it, lc_pipe_wait
+    // for the rare frame that must be classified in full after all).  LANECV_FULL_UPLOAD=1: whole frames always.
+    static const bool full_upload = getenv("LANECV_FULL_UPLOAD") && getenv("LANECV_FULL_UPLOAD")[0] == '1';
+    s->rows_from = full_upload ? 0 : first_row_read(pipe, pipe->nlevels > 0 ? pipe->level : 0);
+    if ((rc = upload_rows(pipe, *s, s->rows_from, pipe->src_h))) return rc;
     return submit(pipe, *s);
 }
 
@@ -314,6 +396,7 @@ int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nfra
     s->nframes = nframes;
     s->input = (const uint8_t *)dev_bgr;
     s->from_host = false;
+    s->rows_from = 0;
     return submit(pipe, *s);
 }
 
@@ -337,6 +420,10 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         if (16 * redone > s->nframes && off_batches > 0 && pipe->level <= s->level) {
             pipe->level = s->level + 1;
             pipe->level_hold = off_batches;
+        }
+        if (!s->eager_redo) {            // the launch could not do it: the frames were not in device memory in full
+            if ((rc = enqueue_repair(pipe, *s))) return rc;
+            if ((rc = wait_event(pipe, slot, s->done))) return rc;
         }
     }
     if (p.want_segments && s->fast_lines && s->h_status[4]) {
@@ -513,6 +600,15 @@ int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_
         else if (pipe->nlevels > 0)
             for (int i = 0; i < s->nframes; i++) *frames_redone += (s->h_rounds[i] >> 30) & 1;
     }
+    return LC_OK;
+}
+
+int lc_pipe_rows_uploaded(lc_pipe *pipe, int slot, int *first_row) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!first_row) return fail(LC_EINVAL, "null output");
+    *first_row = s->from_host ? s->rows_from : 0;
     return LC_OK;
 }
 

@@ -294,6 +294,12 @@ class LanePipeline:
         _abi.check(_abi.lib().lc_pipe_event_times(self._h, slot, out))
         return list(out)
 
+    def rows_uploaded(self, slot):
+        """First row of every frame of the slot's last batch that `submit` copied to the GPU (0: whole frames)."""
+        v = C.c_int()
+        _abi.check(_abi.lib().lc_pipe_rows_uploaded(self._h, slot, C.byref(v)))
+        return v.value
+
     def layout(self):
         """(slots per HoughLinesP launch, HoughLinesP streams, levels of the ROI scheme)."""
         a, b, c = C.c_int(), C.c_int(), C.c_int()

@@ -235,7 +235,10 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out);
 int lc_pipe_destroy(lc_pipe *pipe);
 
 /* Copies nframes BGR frames from host memory (pinned for true overlap) to the
- * slot on its stream and enqueues the whole pipeline behind the copy. */
+ * slot on its stream and enqueues the whole pipeline behind the copy.  host_bgr must
+ * stay valid and unchanged until lc_pipe_wait on the slot returns: the copy is
+ * asynchronous, and with an ROI only the rows the kernels read are copied at first
+ * (the rest of a frame follows in the rare case that it is needed after all). */
 int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes);
 /* Same, but the frames already sit in device memory (no copy is made; the
  * buffer must stay valid and unchanged until lc_pipe_wait on the slot returns: the kernels run some time after
@@ -277,6 +280,10 @@ int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_
  * their own when it was created (HIP folds a process's streams onto GPU_MAX_HW_QUEUES queues; the pipeline probes
  * which ones share).  0 = every stage overlaps as designed; otherwise stages that were meant to run side by side
  * were put on one stream. */
+/* Diagnostics with no counterpart in the reference: the first row of every frame of the slot's last batch that was
+ * copied to the GPU by lc_pipe_submit_host (0: whole frames, also for batches submitted from device memory).  With an
+ * ROI the rows above the first one the kernels read are not copied. */
+int lc_pipe_rows_uploaded(lc_pipe *pipe, int slot, int *first_row);
 int lc_pipe_shared_queues(lc_pipe *pipe, int *count);
 /* Diagnostics with no counterpart in the reference: how the pipeline laid itself out.  *group_size = consecutive slots
  * whose HoughLinesP runs as ONE launch (1: a launch per slot; more for batches that leave most CUs free, see

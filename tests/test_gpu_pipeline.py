@@ -389,6 +389,9 @@ def test_rows_above_the_roi_are_skipped_exactly(oracle, monkeypatch):
         segs = pipe.collect(0)
         masked, acc = pipe.read(0, _abi.BUF_MASKED), pipe.read(0, _abi.BUF_ACC)
         assert pipe.row_skip(0)[1] == want_redone[b], b
+        # (submitted from host memory: only the rows from a little above the first one classified were copied, and the
+        # frames that needed the rows above were fetched in full when the slot was waited for)
+        assert 0 < pipe.rows_uploaded(0) <= first
         for i, f in enumerate(frames):
             r = _oracle_frame(oracle, f, rec, pipe.roi)
             assert (masked[i] == r["masked"]).all(), (b, i)
@@ -493,4 +496,48 @@ def test_short_batch_at_a_level_change_clears_every_frame(oracle, monkeypatch):
             assert (acc[i] == r["acc"]).all(), (b, i)
             got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
             assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (b, i)
+    pipe.close()
+
+
+def test_rows_follow_when_the_level_moves_out_before_the_launch(oracle, monkeypatch):
+    """Frames submitted from host memory are copied from the first row the ROI level of the moment reads.  With two
+    slots to a bank the kernels are queued later, when the bank is full -- and by then the pipeline may have moved to
+    classifying whole frames: the rows that were left out must follow before the launch."""
+    monkeypatch.setenv("LANECV_SKIP_OFF_BATCHES", "50")
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h, B = 960, 540, 4
+    rec = Recipe.north_star(w, h)
+    pipe = LanePipeline(w, h, rec, max_batch=B, nslots=4, seg_capacity=512)
+    assert pipe.layout()[0] == 2
+    g = np.full((h, w), 60, np.int32)
+    g[:100, w // 2 + 40:] += 120
+    g[100:, w // 2 + 40:] += 60
+    faint = np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+    road = [synth.synth_road(w, h, seed=51, t=t) for t in range(2 * B)]
+
+    def check(slot, frames):
+        segs = pipe.collect(slot)
+        masked, acc = pipe.read(slot, _abi.BUF_MASKED), pipe.read(slot, _abi.BUF_ACC)
+        for i, f in enumerate(frames):
+            r = _oracle_frame(oracle, f, rec, pipe.roi)
+            assert (masked[i] == r["masked"]).all() and (acc[i] == r["acc"]).all(), (slot, i)
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (slot, i)
+
+    first = pipe.row_skip(0)[0]
+    a, b_ = np.stack(road[:B]), np.stack(road[B:])
+    pipe.submit(0, a)                              # bank 0, first slot: copied from a little above row `first`, waits for slot 1
+    assert 0 < pipe.rows_uploaded(0) <= first
+    for rnd in range(2):                           # bank 1: frames that need the second pass, twice -> out to whole frames
+        fr = np.stack([faint] * B)
+        pipe.submit(2, fr)
+        pipe.submit(3, fr)
+        check(2, fr)
+        check(3, fr)
+    pipe.submit(1, b_)                             # fills bank 0: its launch classifies whole frames
+    assert pipe.rows_uploaded(1) == 0
+    check(0, a)
+    check(1, b_)
+    assert pipe.rows_uploaded(0) == 0 and pipe.roi_skip(0)[1] == w * h
     pipe.close()
