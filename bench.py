@@ -26,7 +26,7 @@ for p in (ROOT, os.path.join(ROOT, "image-processing_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-W, H, BATCH, NSLOTS, SEG_CAP = 1920, 1080, 256, 4, 128
+W, H, BATCH, NSLOTS, SEG_CAP = 1920, 1080, 256, 6, 128
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak
 
 

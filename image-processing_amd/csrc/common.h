@@ -162,7 +162,10 @@ void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *pla
 // zero before the first (like those buffers); with it, and without edges_out, only what changed is written
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits,
                      uint8_t *edges_out, uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st,
-                     uint64_t *prevbits = nullptr, const FrameSet *fs = nullptr);   // fs: with prevbits only
+                     uint64_t *prevbits = nullptr, const FrameSet *fs = nullptr,   // fs: with prevbits only
+                     // with prevbits and roi_bits: the plane words that hold ROI pixels (row << 8 | word of the row) -- only
+                     // those are then looked at
+                     const uint32_t *roi_words = nullptr, int n_roi_words = 0);
 void launch_and(const uint8_t *a, const uint8_t *b, const uint8_t *mask, uint8_t *dst, size_t n, hipStream_t st);
 void launch_pack_nonzero(const uint8_t *img, Geo g, int nframes, uint64_t *rowplane, int *rowcount, hipStream_t st);
 // points + Hough

@@ -11,6 +11,7 @@
 //   hysteresis: 8-connected closure from strong through weak pixels
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace lanecv {
 namespace {
@@ -488,25 +489,33 @@ __global__ __launch_bounds__(HC_THREADS) void k_hysteresis(Geo g, uint64_t *__re
                                                            const uint64_t *__restrict__ planeW,
                                                            uint32_t *__restrict__ wakeA, uint32_t *__restrict__ wakeB,
                                                            int *__restrict__ rounds_out, int *__restrict__ status,
-                                                           const int *__restrict__ only_frames, RingArgs ra, FrameSet fs) {
+                                                           const int *__restrict__ only_frames, RingArgs ra, FrameSet fs, int nframes) {
     __shared__ int any, count;
+#ifdef LC_POST_PRIO
+    __builtin_amdgcn_s_setprio(LC_POST_PRIO);
+#endif
     __shared__ uint32_t px[RING_LIST];
-    const int f = blockIdx.x;
-    if (!fs.has(f)) return;
-    if (status) status += 8 * fs.part(f);            // every part has status words of its own
-    if (status && !only_frames && fs.first_of_part(f) && threadIdx.x < 5) status[threadIdx.x] = 0;
-    if (only_frames && only_frames[f] == 0) return;
-    const int rounds = hysteresis_frame(g, f, planeS, planeW, wakeA, wakeB, any);
-    bool bad = false;
-    if (ra.redo) {
-        __syncthreads();
-        bad = ring_check_frame(g, f, planeS, planeW, ra, px, count);
-    }
-    if (threadIdx.x == 0) {
-        if (ra.redo) ra.redo[f] = bad ? 1 : 0;
-        if (bad && status) status[3] = 1;        // (plain stores: the words may live in host memory)
-        // bit 30 of the rounds word: the frame is, or (second pass over flagged frames) was, flagged
-        if (rounds_out) rounds_out[f] = rounds | ((bad || only_frames) ? 0x40000000 : 0);
+    // every frame: the workgroup's one frame.  Flagged frames only (only_frames): a few workgroups that go through the
+    // frames looking the flags up -- nearly always none is set, and a workgroup of this size per frame that only reads a
+    // flag still has to find a CU with room for it
+    for (int f = blockIdx.x; f < nframes; f += gridDim.x) {
+        if (!fs.has(f)) continue;
+        int *st = status ? status + 8 * fs.part(f) : nullptr;            // every part has status words of its own
+        if (st && !only_frames && fs.first_of_part(f) && threadIdx.x < 5) st[threadIdx.x] = 0;
+        if (only_frames && only_frames[f] == 0) continue;
+        __syncthreads();                                                  // (the LDS words of the frame before)
+        const int rounds = hysteresis_frame(g, f, planeS, planeW, wakeA, wakeB, any);
+        bool bad = false;
+        if (ra.redo) {
+            __syncthreads();
+            bad = ring_check_frame(g, f, planeS, planeW, ra, px, count);
+        }
+        if (threadIdx.x == 0) {
+            if (ra.redo) ra.redo[f] = bad ? 1 : 0;
+            if (bad && st) st[3] = 1;        // (plain stores: the words may live in host memory)
+            // bit 30 of the rounds word: the frame is, or (second pass over flagged frames) was, flagged
+            if (rounds_out) rounds_out[f] = rounds | ((bad || only_frames) ? 0x40000000 : 0);
+        }
     }
 }
 
@@ -607,6 +616,9 @@ __global__ __launch_bounds__(256) void k_finalize_sparse(Geo g, size_t nwords, c
                                                          const uint64_t *__restrict__ roi_bits, uint64_t *__restrict__ prevbits,
                                                          uint8_t *__restrict__ masked_out, uint64_t *__restrict__ rowplane,
                                                          int *__restrict__ rowcount, FrameSet fs) {
+#ifdef LC_POST_PRIO
+    __builtin_amdgcn_s_setprio(LC_POST_PRIO);
+#endif
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nwords) return;
     const size_t words_per_frame = (size_t)g.TX * g.H;
@@ -617,6 +629,23 @@ __global__ __launch_bounds__(256) void k_finalize_sparse(Geo g, size_t nwords, c
     const uint64_t P = prevbits[i];
     if (M && rowcount) atomicAdd(&rowcount[f * g.H + wf / g.TX], __popcll(M));
     finalize_word(g, f, wf, i, M, P, prevbits, masked_out, rowplane);
+}
+
+// The same over the plane words that hold ROI pixels only (listed once per pipeline as row << 8 | word of the row): the
+// other words' masked bits are zero now and were zero last time, so there is nothing to look at -- with the
+// triangle three quarters of a frame's words.  One thread per listed word, blockIdx.y = frame.
+__global__ __launch_bounds__(256) void k_finalize_roi(Geo g, const uint32_t *__restrict__ roi_words, int nlist,
+                                                      const uint64_t *__restrict__ planeS, const uint64_t *__restrict__ roi_bits,
+                                                      uint64_t *__restrict__ prevbits, uint8_t *__restrict__ masked_out,
+                                                      uint64_t *__restrict__ rowplane, int *__restrict__ rowcount, FrameSet fs) {
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x), f = (int)blockIdx.y;
+    if (k >= nlist || !fs.has(f)) return;
+    const uint32_t e = roi_words[k];
+    const int y = (int)(e >> 8);
+    const size_t wf = (size_t)y * g.TX + (e & 255u), i = (size_t)f * g.TX * g.H + wf;
+    const uint64_t M = planeS[i] & roi_bits[wf], P = prevbits[i];
+    if (M && rowcount) atomicAdd(&rowcount[(size_t)f * g.H + y], __popcll(M));
+    finalize_word(g, (size_t)f, wf, i, M, P, prevbits, masked_out, rowplane);
 }
 
 // bitwise_and with an optional mask (dst = 0 where mask == 0)
@@ -704,12 +733,18 @@ void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *pla
     // exit (zeroed when allocated): the kernel clears every flag it consumes and stops when a round sets none.
     const int nt = g.TX * g.TY * nframes;
     const RingArgs ra{ring_words, nring_words, ring_code, ring_code ? redo : nullptr};
-    hipLaunchKernelGGL(k_hysteresis, dim3(nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake, wake + nt, rounds, status, only_frames, ra,
-                       fs ? *fs : FrameSet{});
+    hipLaunchKernelGGL(k_hysteresis, dim3(only_frames ? std::min(nframes, 8) : nframes), dim3(HC_THREADS), 0, st, g, planeS, planeW, wake,
+                       wake + nt, rounds, status, only_frames, ra, fs ? *fs : FrameSet{}, nframes);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,
-                     uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st, uint64_t *prevbits, const FrameSet *fs) {
+                     uint8_t *masked_out, uint64_t *rowplane, int *rowcount, hipStream_t st, uint64_t *prevbits, const FrameSet *fs,
+                     const uint32_t *roi_words, int n_roi_words) {
+    if (prevbits && !edges_out && masked_out && roi_bits && roi_words && n_roi_words > 0) {
+        hipLaunchKernelGGL(k_finalize_roi, dim3((unsigned)((n_roi_words + 255) / 256), (unsigned)nframes), dim3(256), 0, st, g, roi_words,
+                           n_roi_words, planeS, roi_bits, prevbits, masked_out, rowplane, rowcount, fs ? *fs : FrameSet{});
+        return;
+    }
     if (prevbits && !edges_out && masked_out) {
         const size_t nwords = (size_t)g.TX * g.H * nframes;
         hipLaunchKernelGGL(k_finalize_sparse, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, g, nwords, planeS, roi_bits,

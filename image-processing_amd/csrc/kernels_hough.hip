@@ -33,6 +33,9 @@ __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint6
                                                                int *__restrict__ rowcount, uint32_t *__restrict__ nz, int nz_cap,
                                                                int *__restrict__ npoints, int *__restrict__ status, FrameSet fs) {
     __shared__ int tot[POINTS_WAVES];
+#ifdef LC_POST_PRIO
+    __builtin_amdgcn_s_setprio(LC_POST_PRIO);
+#endif
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (!fs.has(f)) return;
     if (status) status += 8 * fs.part(f);
@@ -233,6 +236,7 @@ struct Walk {
 
 #ifdef LC_STAMPS
 __device__ long long g_stamps[8];   // diagnostic build only: cycle sums of frame 0
+__device__ long long g_more[8];     // frame 0: vote groups, alive points at batch starts, cycles between trigger and walk, batches with a trigger, segments
 __device__ unsigned long long g_dbg[4];
 __device__ int g_simd[8];
 __device__ long long g_setup[16];             // frame 0: cycles since kernel start at the marks of the set-up
@@ -1093,6 +1097,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     int nseg = 0, jobseq = 0;
 #ifdef LC_STAMPS
     long long t_wait = 0, t_vote = 0, t_line = 0, n_alive = 0, n_line = 0, tc0 = STAMP();
+    long long n_groups = 0, t_pre = 0, n_trig_batches = 0;
 #endif
     for (int k = 0; k < n; k += 64) {
         const int m = min(64, n - k);
@@ -1113,6 +1118,8 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         uint64_t alive = __ballot(alive_l);
 #ifdef LC_STAMPS
         t_wait += STAMP() - tw;
+        n_alive += __popcll(alive);
+        bool trig_here = false;
 #endif
         while (alive) {
             constexpr int Q = PPHT_Q;
@@ -1149,6 +1156,8 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
             }
 #ifdef LC_STAMPS
             t_vote += STAMP() - tv;
+            n_groups++;
+            long long tpre = STAMP();
 #endif
             if (any) {
                 int hit = Q - 1;   // first point of the group, in OpenCV's order, that starts a line
@@ -1170,7 +1179,9 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
                     if (e > hit) atomicSub(&words[widx[e]], inc[e]);
 #ifdef LC_STAMPS
                 long long tl = STAMP();
+                t_pre += tl - tpre;
                 n_line++;
+                if (!trig_here) { trig_here = true; n_trig_batches++; }
 #endif
                 LineOut lo;
                 const int lr = extract_line<true, PPHT_WAVES>(c, lane, (int)(hpt & 0xFFFF), (int)(hpt >> 16), max_n, nseg, &jobs, jobseq, vl, lo);
@@ -1195,6 +1206,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     if (f == 0 && lane == 0) {
         g_stamps[1] = STAMP() - tc0; g_stamps[2] = t_wait; g_stamps[3] = t_vote; g_stamps[4] = t_line;
         g_stamps[5] = n_alive; g_stamps[6] = n_line; g_stamps[7] = n;
+        g_more[0] = n_groups; g_more[1] = n_alive; g_more[2] = t_pre; g_more[3] = n_trig_batches; g_more[4] = nseg;
     }
     if (f < 512 && lane == 0) { g_frame_cycles[2 * f] = STAMP() - tc0; g_frame_cycles[2 * f + 1] = STAMP() - t_kernel0; }
 #endif
@@ -1303,6 +1315,7 @@ void launch_ppht_general(Geo g, int nframes, uint32_t *nz, int nz_cap, const int
 extern "C" int lc_debug_stamps(long long *out) {
     (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_dbg), sizeof(long long) * 4);
     (void)hipMemcpyFromSymbol(out + 12, HIP_SYMBOL(g_simd), sizeof(int) * 8);
+    (void)hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_more), sizeof(long long) * 8);
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 8);
 }
 extern "C" int lc_debug_setup(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup), sizeof(long long) * 16); }

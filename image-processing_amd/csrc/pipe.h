@@ -49,6 +49,8 @@ struct lc_pipe {
     Geo g{};
     int low = 0, high = 0, line_length = 0, line_gap = 0;
     DevBuf<uint64_t> roi_bits;
+    DevBuf<uint32_t> roi_words;   // the plane words that hold ROI pixels, row << 8 | word of the row (what finalize looks at)
+    int n_roi_words = 0;
     bool has_roi = false;
     bool has_gate = false;        // colour gate in front of the gray conversion
     GateDev gate{};
@@ -82,6 +84,12 @@ struct lc_pipe {
     // LANECV_LINES_STREAMS overrides the count.
     std::vector<hipStream_t> st_lines_more;
     unsigned lines_turn = 0;
+    // Tail streams: the short kernels behind a front kernel run on the HoughLinesP stream of their own launch instead of
+    // a post stream shared by all launches (they precede that launch's HoughLinesP anyway), which leaves a hardware queue
+    // for a third HoughLinesP stream: while one launch's short kernels wait for room beside a front kernel, the other
+    // streams' HoughLinesP kernels run on, and a third launch fills the CUs the slowest frames of the first leave idle.
+    bool tail_streams = false;
+    bool hyst_on_edge = false;    // with tail streams: hysteresis stays on the edge stream, behind its front kernel
     // The streaming front kernel's unit height (fixed for the pipeline's largest batch: its change tracking is per unit)
     // and, for pipelines with an ROI, which units it classifies at all.  The final edge map is the hysteresis result
     // INSIDE the ROI, and that depends on pixels outside it only through weak pixels that connect the two.  The front

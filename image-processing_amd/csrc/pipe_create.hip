@@ -86,6 +86,16 @@ int setup_roi(lc_pipe *pp, const lc_pipe_params &p, std::vector<uint64_t> &bits)
         if ((rc = pp->roi_bits.alloc(bits.size()))) return rc;
         hipError_t e = hipMemcpy(pp->roi_bits.p, bits.data(), bits.size() * 8, hipMemcpyHostToDevice);
         if (e != hipSuccess) return fail(LC_EHIP, "roi upload failed: %s", hipGetErrorString(e));
+        std::vector<uint32_t> words;
+        for (int y = 0; y < g.H; y++)
+            for (int tx = 0; tx < g.TX; tx++)
+                if (bits[(size_t)y * g.TX + tx]) words.push_back((uint32_t)y << 8 | (uint32_t)tx);
+        if (!words.empty() && g.TX <= 256) {
+            if ((rc = pp->roi_words.alloc(words.size()))) return rc;
+            e = hipMemcpy(pp->roi_words.p, words.data(), words.size() * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(LC_EHIP, "roi upload failed: %s", hipGetErrorString(e));
+            pp->n_roi_words = (int)words.size();
+        }
         pp->has_roi = true;
     }
     return LC_OK;
@@ -264,7 +274,19 @@ int setup_streams(lc_pipe *pp) {
         // front kernel then starts at once and they run beside it (LANECV_POST_STREAM=0: keep them on st_edge)
         pp->st_post = pp->st_edge;
         const char *po = getenv("LANECV_POST_STREAM");
-        if (pp->banks.size() > 1 && !(po && po[0] == '0')) {
+        // Pipelines with three banks or more run the short kernels of a launch on that launch's own HoughLinesP stream
+        // (see lc_pipe::tail_streams) and hysteresis on the edge stream.  LANECV_TAIL_STREAMS=0: the post stream
+        // layout for them too; =1: hysteresis on the tail streams as well (it then waits for room beside the next
+        // front kernel: measured slower).
+        const char *ts = getenv("LANECV_TAIL_STREAMS");
+        // (Not for launches whose front kernel is no longer than the hysteresis kernel behind it -- 960 x 540 frames in
+        // batches of 256: 1.12 M frames/s with the post stream, 1.01 M with this; 1280 x 720: 0.78 M against 0.85 M.)
+        const long long classified = (pp->nlevels > 0 ? pp->levels[0].pixels : pp->frame_pixels) * (long long)pp->bank_frames;
+        const bool long_front = pp->parts > 1 || classified >= 64ll << 20;
+        pp->tail_streams = own_lines && pp->banks.size() >= 3 && (ts ? ts[0] != '0' : long_front);
+        pp->hyst_on_edge = pp->tail_streams && !(ts && ts[0] == '1');
+        if (pp->tail_streams) pp->st_post = pp->st_lines;
+        else if (pp->banks.size() > 1 && !(po && po[0] == '0')) {
             hipStream_t st = picker.pick(mine, &own);
             if (st && own) { pp->st_post = st; mine.push_back(st); }
             else {                                  // no queue of its own: behind the front kernels, as with one slot
@@ -275,7 +297,8 @@ int setup_streams(lc_pipe *pp) {
         if (own_lines) {
             int want = 1;
             if (pp->cu_count > 0)
-                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * pp->cu_count / pp->bank_frames, (int)pp->banks.size()), 3));
+                want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * pp->cu_count / pp->bank_frames + (pp->tail_streams ? 1 : 0),
+                                                     (int)pp->banks.size()), 3));
             const char *ns = getenv("LANECV_LINES_STREAMS");
             if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
             for (int k = 1; k < want; k++) {
@@ -415,7 +438,7 @@ int lc_pipe_destroy(lc_pipe *pipe) {
     if (pipe->st_edge) (void)hipStreamSynchronize(pipe->st_edge);
     if (pipe->st_lines) (void)hipStreamSynchronize(pipe->st_lines);
     for (hipStream_t st : pipe->st_lines_more) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    if (pipe->st_post && pipe->st_post != pipe->st_edge) { (void)hipStreamSynchronize(pipe->st_post); (void)hipStreamDestroy(pipe->st_post); }
+    if (pipe->st_post && pipe->st_post != pipe->st_edge && pipe->st_post != pipe->st_lines) { (void)hipStreamSynchronize(pipe->st_post); (void)hipStreamDestroy(pipe->st_post); }
     for (Slot &s : pipe->slots) if (s.done) (void)hipEventDestroy(s.done);
     for (Bank &bk : pipe->banks) {
         for (auto &ev : bk.ev) if (ev) (void)hipEventDestroy(ev);

@@ -38,7 +38,7 @@ void enqueue_post(lc_pipe *pp, Bank &bk, const Launch &L, hipStream_t es) {
             if (L.fs.count[j])
                 (void)hipMemsetAsync(w.rowcount.p + (size_t)j * p.max_batch * w.g.H, 0, sizeof(int) * (size_t)L.fs.count[j] * w.g.H, es);
     launch_finalize(w.g, n, w.planeS.p, pp->has_roi ? pp->roi_bits.p : nullptr, w.inter ? w.edges.p : nullptr, w.masked.p,
-                    w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p, &L.fs);
+                    w.rowplane.p, w.rowcount.p, es, w.inter ? nullptr : w.prevbits.p, &L.fs, pp->roi_words.p, pp->n_roi_words);
     stamp(pp, bk, EV_EDGE, es);
     if (points) launch_points(w.g, n, w.rowplane.p, w.rowcount.p, w.nz.p, w.nz_cap, w.npoints.p, w.r_status, es, &L.fs);
     // The full-vote accumulator depends only on the point list.  With segments wanted, the HoughLinesP kernel
@@ -142,6 +142,8 @@ int launch_bank(lc_pipe *pp, int bi) {
     if (L.nframes == 0) return LC_OK;
     const int n = L.nframes;
     hipStream_t es = pp->st_edge, ps = pp->st_post;
+    hipStream_t ls = next_lines_stream(pp);
+    if (pp->tail_streams) ps = ls;            // the launch's short kernels share its HoughLinesP stream
     if (pp->level > 0 && pp->nlevels > 0) {
         if (pp->level_hold > 0) pp->level_hold--;
         else { pp->level--; pp->level_hold = 0; }     // try one level in again
@@ -199,25 +201,27 @@ int launch_bank(lc_pipe *pp, int bi) {
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
                  pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize, pp->front_rows,
                  pp->nlevels > 0 ? &skip : nullptr, &L.fs, L.src);
-    if (ps != es || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_FRONT], es));
-    if (ps != es) HIP_TRY(hipStreamWaitEvent(ps, bk.ev[EV_FRONT], 0));
+    // hysteresis runs on hs: the post (or tail) stream, or the edge stream itself (behind its front kernel, before the next)
+    hipStream_t hs = pp->hyst_on_edge ? es : ps;
+    if (hs != es || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_FRONT], es));
+    if (hs != es) HIP_TRY(hipStreamWaitEvent(hs, bk.ev[EV_FRONT], 0));
     // Hysteresis; with an ROI level active the frame's workgroup then proves that the units classified settle the ROI's
     // edges, or flags the frame (rare).  Flagged frames: all units again, and their hysteresis -- two launches that
     // leave at once for the other frames, which is nearly always all of them.  (What the full passes leave in the plane
     // rows of units the level does not classify is cleared before the bank's next launch: lc_pipe_wait sees the flag.)
     const lc_pipe::SkipLevel *SL = skipping ? &pp->levels[L.level] : nullptr;
-    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, w.r_status, nullptr, SL ? SL->ring_words.p : nullptr,
+    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, hs, w.r_status, nullptr, SL ? SL->ring_words.p : nullptr,
                       SL ? SL->n_ring_words : 0, SL ? SL->ring_code.p : nullptr, w.redo.p, &L.fs);
     if (skipping && eager) {
         const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
         launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
-                     nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize,
+                     nullptr, nullptr, hs, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize,
                      pp->front_rows, &again, &L.fs, L.src);
-        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs);
+        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, hs, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs);
     }
-    stamp(pp, bk, EV_HYST, ps);
+    if (hs != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_HYST], hs));
+    if (hs != ps) HIP_TRY(hipStreamWaitEvent(ps, bk.ev[EV_HYST], 0));
     enqueue_post(pp, bk, L, ps);
-    hipStream_t ls = next_lines_stream(pp);
     const int ready = (p.want_accumulator && !vote_is_fused(pp)) ? EV_VOTE : EV_POINTS;
     if (ls != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[ready], ps));
     if (pp->timing && ready == EV_POINTS && !vote_is_fused(pp)) (void)hipEventRecord(bk.ev[EV_VOTE], ps);
@@ -243,7 +247,7 @@ int upload_stream(lc_pipe *pipe) {
         if (s.busy) { HIP_TRY(hipStreamCreateWithFlags(&pipe->st_up, hipStreamNonBlocking)); return LC_OK; }   // no experiments beside work in flight
     StreamPicker picker;
     std::vector<hipStream_t> mine = {pipe->st_edge};
-    if (pipe->st_post != pipe->st_edge) mine.push_back(pipe->st_post);
+    if (pipe->st_post != pipe->st_edge && pipe->st_post != pipe->st_lines) mine.push_back(pipe->st_post);
     if (pipe->st_lines != pipe->st_edge) mine.push_back(pipe->st_lines);
     for (hipStream_t st : pipe->st_lines_more) mine.push_back(st);
     bool own = true;

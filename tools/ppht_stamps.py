@@ -8,14 +8,14 @@ from lanecv.pipeline import LanePipeline, Recipe
 w,h=1920,1080
 rec=Recipe.north_star(w,h)
 B=int(sys.argv[1]) if len(sys.argv)>1 else 32
-pipe=LanePipeline(w,h,rec,max_batch=B,nslots=1, timing=True)
+pipe=LanePipeline(w,h,rec,max_batch=B,nslots=int(os.environ.get('STAMP_SLOTS','1')), timing=True)
 fr=np.stack([synth.synth_road(w,h,100,t) for t in range(B)])
 for it in range(1):
     pipe.submit(0, fr); pipe.collect(0)
 out=(C.c_longlong*48)()
 print('rc', _abi.lib().lc_debug_stamps(out))
 names=['producer_cycles','consumer_cycles','wait','vote','line','n_alive','n_line','n']
-print({k:int(v) for k,v in zip(names,out)}); print('dbg', list(out)[8:12]); import struct; print('simd', struct.unpack('8i', struct.pack('4q', *list(out)[12:16])))
+print({k:int(v) for k,v in zip(names,out)}); print('dbg walk/clear/removal wait/tail', list(out)[8:12]); print('groups, alive points, cycles trigger->walk, batches with a trigger, segments', list(out)[16:21]); import struct; print('simd', struct.unpack('8i', struct.pack('4q', *list(out)[12:16])))
 print('lines ms', pipe.stage_ms(0,_abi.STAGE_LINES))
 fc = (C.c_longlong * (2 * B))()
 _abi.lib().lc_debug_frame_cycles(fc, B)
