@@ -33,9 +33,6 @@ __global__ __launch_bounds__(64 * POINTS_WAVES) void k_points(Geo g, const uint6
                                                                int *__restrict__ rowcount, uint32_t *__restrict__ nz, int nz_cap,
                                                                int *__restrict__ npoints, int *__restrict__ status, FrameSet fs) {
     __shared__ int tot[POINTS_WAVES];
-#ifdef LC_POST_PRIO
-    __builtin_amdgcn_s_setprio(LC_POST_PRIO);
-#endif
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (!fs.has(f)) return;
     if (status) status += 8 * fs.part(f);
@@ -1262,7 +1259,15 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
                        numrho, apg, acc, flags, fs ? *fs : FrameSet{});
 }
 
-int ppht_lds_half() { return PPHT_LDS_HALF; }
+int ppht_lds_half() {
+    // LANECV_PPHT_LDS_KB (diagnostics, 16 .. 72): another size for the shared-CU launches, e.g. 48 for three frames per CU
+    static const int kb = [] {
+        const char *e = getenv("LANECV_PPHT_LDS_KB");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 16 && v <= 72) ? v : 0;
+    }();
+    return kb ? kb * 1024 : PPHT_LDS_HALF;
+}
 
 // HoughLinesP in two steps, so that the caller can put the flagged vote kernel between them (the general
 // kernel permutes the point list in place).  flags[f]: bit 0 = the general kernel must do frame f,

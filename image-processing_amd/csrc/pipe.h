@@ -115,6 +115,10 @@ struct lc_pipe {
     };
     SkipLevel levels[2];
     int nlevels = 0, level = 0, level_hold = 0;
+    // Launches queue the second pass over flagged frames (the front kernel again, hysteresis again: two launches that
+    // find nothing to do when no frame is flagged) only while flagged frames are about -- for this many launches after
+    // lc_pipe_wait last saw one.  Otherwise a flagged frame is made up for when its slot is waited for (enqueue_repair).
+    int redo_hold = 0;
     DevBuf<int> ones;
     long long frame_pixels = 0;
     FrontSplit split(int lvl, int mode, const int *only) const {

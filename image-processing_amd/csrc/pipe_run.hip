@@ -166,6 +166,9 @@ int launch_bank(lc_pipe *pp, int bi) {
         }
         eager = eager && s.rows_from == 0;
     }
+    static const bool always_eager = getenv("LANECV_EAGER_REDO") && getenv("LANECV_EAGER_REDO")[0] == '1';   // diagnostics
+    if (pp->redo_hold > 0) pp->redo_hold--;
+    else if (!always_eager) eager = false;
     if (from_host) {
         HIP_TRY(hipEventRecord(bk.ev[EV_UPLOADED], pp->st_up));     // behind the copies of every pending slot
         HIP_TRY(hipStreamWaitEvent(es, bk.ev[EV_UPLOADED], 0));
@@ -417,6 +420,7 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         // passes stored plane rows in units the level does not classify: cleared before the bank's next launch.  And a
         // batch with many of them moves the pipeline a level out.
         pipe->banks[s->bank].planes_level = pipe->nlevels;
+        pipe->redo_hold = 64;
         int redone = 0;
         for (int i = 0; i < s->nframes; i++) redone += (s->h_rounds[i] >> 30) & 1;
         const char *ob = getenv("LANECV_SKIP_OFF_BATCHES");         // diagnostics / tests; 0 = never move a level out
