@@ -111,11 +111,33 @@ struct FrontSplit {
 // the unit grid of a frame for a unit height and a split row (what launch_front_stream uses; for building unit lists)
 struct FrontGrid { int nseg_top, rows_top, nseg_low, rows_low, nstrips, strip_cols; };
 FrontGrid front_stream_grid(Geo g, int rows_per_unit, int row_split);
+// A hysteresis launch (the arguments of launch_hysteresis below) that a streaming front-kernel launch carries as its
+// first workgroups: the hysteresis of the batch BEFORE the one the front kernel classifies, one workgroup of 128 threads
+// per frame, beside the front kernel's own units instead of between two front kernels.  px_scratch: RING_LIST_WORDS
+// words per frame of device memory (the ring check's pixel list, which the stand-alone kernel keeps in LDS).
+constexpr int RING_LIST_WORDS = 256;
+struct HystLaunch {
+    Geo g;
+    int nframes;
+    uint64_t *planeS;
+    const uint64_t *planeW;
+    uint32_t *wake;
+    int *rounds, *status;
+    const uint32_t *ring_words;
+    int nring_words;
+    const uint64_t *ring_code;
+    int *redo;
+    uint32_t *px_scratch;
+    FrameSet fs;
+    int wake_frames;         // see launch_hysteresis
+};
+// whether launch_front would hand a launch of this kind to the streaming kernel (the only one that can carry a lead)
+bool front_takes_lead(Geo g, int in_kind);
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                          int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags = nullptr,
                          bool dec3 = false, const FrontSplit *split = nullptr, const FrameSet *fs = nullptr,
-                         const uint8_t *const *src_parts = nullptr);
+                         const uint8_t *const *src_parts = nullptr, const HystLaunch *lead = nullptr);
 // fs / src_parts (may be null): the frames that take part, and where each part's frames start (src is ignored then)
 // dec3: src holds frames of 3 W x 3 H pixels; the kernel takes source pixel (3x + 1, 3y + 1) for pixel (x, y), which is
 // what cv2.resize's bilinear reduction by exactly three yields (no gate, no intermediate images in this form)
@@ -133,7 +155,8 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
                   uint8_t *gray_out, uint8_t *blur_out, hipStream_t st,
                   const GateDev *gate = nullptr, const int *tab = nullptr, uint8_t *gate_gray = nullptr,
                   uint8_t *rowflags = nullptr, bool dec3 = false, int rows_per_unit = 0, const FrontSplit *split = nullptr,
-                  const FrameSet *fs = nullptr, const uint8_t *const *src_parts = nullptr);
+                  const FrameSet *fs = nullptr, const uint8_t *const *src_parts = nullptr, const HystLaunch *lead = nullptr);
+// lead (streaming kernel, no intermediates, not a flag-checking launch): see HystLaunch
 // rows_per_unit (streaming kernel; 0 = derived from nframes): pipelines pass the value of their largest batch, so that
 // the unit grid -- and with it the per-unit change tracking behind rowflags -- does not move with the batch size
 // hysteresis to the fixed point: one workgroup per frame floods the tiles flagged in wake (by the front
@@ -155,7 +178,10 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st, int *status = nullptr, const int *only_frames = nullptr,
                        const uint32_t *ring_words = nullptr, int nring_words = 0, const uint64_t *ring_code = nullptr,
-                       int *redo = nullptr, const FrameSet *fs = nullptr);
+                       int *redo = nullptr, const FrameSet *fs = nullptr, int wake_frames = 0);
+// wake_frames: the frames the wake buffer was sized for (the second flag array starts behind that many frames' flags);
+// 0 = nframes.  Launches over a part of a buffer's frames must pass it: the second array of a shorter launch would
+// otherwise lie where the front kernel of another launch sets the flags of the frames behind.
 // fs (may be null): the frames that take part; every part then has status words of its own, status + 8 * part
 // roi_bits: one plane shared by all frames, or nullptr
 // prevbits (may be null): the masked bits of the previous call on the same masked_out / rowplane buffers, all

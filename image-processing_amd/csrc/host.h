@@ -74,6 +74,7 @@ struct Work {
     DevBuf<uint32_t> wake;        // two wake-flag arrays of B * tiles words (hysteresis closure)
     DevBuf<int> rounds, rowcount, npoints, segcount, status, fallback;
     DevBuf<int> redo;             // per frame: the pass over the lower rows only was not enough (pipelines that skip rows)
+    DevBuf<uint32_t> ring_px;     // per frame: the ring check's pixel list when hysteresis leads a front launch (HystLaunch)
     DevBuf<uint32_t> nz;
     int nz_cap = 0;
     DevBuf<int32_t> acc_full, acc_ppht, seg;
@@ -138,6 +139,7 @@ struct Work {
         if ((rc = status.alloc(8))) return rc;
         if ((rc = redo.alloc(B))) return rc;
         HIP_TRY(hipMemset(redo.p, 0, sizeof(int) * (size_t)B));
+        if ((rc = ring_px.alloc((size_t)B * RING_LIST_WORDS))) return rc;
         if ((rc = fallback.alloc(B))) return rc;
         return LC_OK;
     }

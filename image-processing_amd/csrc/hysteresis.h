@@ -179,7 +179,7 @@ __device__ __forceinline__ int hysteresis_frame(const Geo &g, int f, uint64_t *_
 // of the ROI -- and floods from them through 8-neighbours in the list (a thread per listed pixel); only if the flood
 // arrives in ring 15, or does not settle, or the list overflows, is the frame classified again in full.
 // ---------------------------------------------------------------------------
-constexpr int RING_LIST = 256, RING_ROUNDS = 48;   // beyond either the frame is classified in full rather than looked at longer
+constexpr int RING_LIST = RING_LIST_WORDS, RING_ROUNDS = 48;   // beyond either the frame is classified in full rather than looked at longer
 struct RingArgs {
     const uint32_t *ring_words;     // indices of the plane words that hold ring pixels
     int nring_words;
@@ -188,7 +188,10 @@ struct RingArgs {
 };
 
 // px: RING_LIST words of LDS, count: one; returns (to every thread) whether frame f must be classified again
-template <int HC_THREADS>
+// PXG: the list lives in device memory (read and written through L2) instead of LDS
+template <bool PXG> __device__ __forceinline__ uint32_t ld_px(const uint32_t *p) { if constexpr (PXG) return ldF(p); else return *p; }
+template <bool PXG> __device__ __forceinline__ void st_px(uint32_t *p, uint32_t v) { if constexpr (PXG) stF(p, v); else *p = v; }
+template <int HC_THREADS, bool PXG = false>
 __device__ __forceinline__ bool ring_check_frame(const Geo &g, int f, const uint64_t *__restrict__ planeS,
                                                  const uint64_t *__restrict__ planeW, const RingArgs &ra, uint32_t *px, int &count) {
     const int tid = threadIdx.x;
@@ -211,7 +214,7 @@ __device__ __forceinline__ bool ring_check_frame(const Geo &g, int f, const uint
             const uint32_t ring = (uint32_t)((c0 >> b) & 1) | (uint32_t)((c1 >> b) & 1) << 1 | (uint32_t)((c2 >> b) & 1) << 2 |
                                   (uint32_t)((c3 >> b) & 1) << 3;
             // x | y << 13 | ring << 26 | reached << 31
-            if (at + k < RING_LIST) px[at + k] = (xb + b) | (y << 13) | (ring << 26) | ((ring == 1 ? 1u : 0u) << 31);
+            if (at + k < RING_LIST) st_px<PXG>(px + at + k, (xb + b) | (y << 13) | (ring << 26) | ((ring == 1 ? 1u : 0u) << 31));
         }
     }
     __syncthreads();
@@ -226,7 +229,7 @@ __device__ __forceinline__ bool ring_check_frame(const Geo &g, int f, const uint
     for (int q = 0; q < PER; q++) {
         const int idx = tid + q * HC_THREADS;
         mine[q] = idx < n;
-        p0[q] = mine[q] ? px[idx] : 0u;
+        p0[q] = mine[q] ? ld_px<PXG>(px + idx) : 0u;
         reached[q] = (p0[q] >> 31) != 0;
     }
     bool settled = false;
@@ -238,10 +241,10 @@ __device__ __forceinline__ bool ring_check_frame(const Geo &g, int f, const uint
             const int x = p0[q] & 0x1FFF, y = (p0[q] >> 13) & 0x1FFF;
             bool hit = false;
             for (int j = 0; j < n && !hit; j++) {
-                const uint32_t v = px[j];        // (another thread may be setting its bit 31 right now: sooner or later is the same)
+                const uint32_t v = ld_px<PXG>(px + j);        // (another thread may be setting its bit 31 right now: sooner or later is the same)
                 hit = (v >> 31) && abs((int)(v & 0x1FFF) - x) <= 1 && abs((int)((v >> 13) & 0x1FFF) - y) <= 1;
             }
-            if (hit) { reached[q] = true; px[tid + q * HC_THREADS] = p0[q] | 0x80000000u; changed = true; }
+            if (hit) { reached[q] = true; st_px<PXG>(px + tid + q * HC_THREADS, p0[q] | 0x80000000u); changed = true; }
         }
         settled = __syncthreads_or(changed ? 1 : 0) == 0;
     }
@@ -268,7 +271,7 @@ struct HystArgs {
 // One frame of a hysteresis launch, by the HC_THREADS threads of a workgroup: the rounds, the proof that the units
 // classified settle the ROI's edges (ra.redo set), the frame's words of the result block.  any, count: a word of LDS
 // each; px: RING_LIST words.  All threads of the workgroup must call it together.
-template <int HC_THREADS>
+template <int HC_THREADS, bool PXG = false>
 __device__ __forceinline__ void hysteresis_one_frame(const HystArgs &h, int f, int &any, int &count, uint32_t *px) {
     if (!h.fs.has(f)) return;
     int *st = h.status ? h.status + 8 * h.fs.part(f) : nullptr;            // every part has status words of its own
@@ -279,7 +282,7 @@ __device__ __forceinline__ void hysteresis_one_frame(const HystArgs &h, int f, i
     bool bad = false;
     if (h.ra.redo) {
         __syncthreads();
-        bad = ring_check_frame<HC_THREADS>(h.g, f, h.planeS, h.planeW, h.ra, px, count);
+        bad = ring_check_frame<HC_THREADS, PXG>(h.g, f, h.planeS, h.planeW, h.ra, px, count);
     }
     if (threadIdx.x == 0) {
         if (h.ra.redo) h.ra.redo[f] = bad ? 1 : 0;
@@ -291,13 +294,13 @@ __device__ __forceinline__ void hysteresis_one_frame(const HystArgs &h, int f, i
 
 inline HystArgs hysteresis_args(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds, int *status,
                                 const int *only_frames, const uint32_t *ring_words, int nring_words, const uint64_t *ring_code,
-                                int *redo, const FrameSet *fs) {
+                                int *redo, const FrameSet *fs, int wake_frames = 0) {
     // wake holds two flag arrays of nframes * tiles words each.  The second is all zero on entry and both are on
     // exit (zeroed when allocated): the kernel clears every flag it consumes and stops when a round sets none.
     HystArgs h;
     h.g = g;
     h.planeS = planeS; h.planeW = planeW;
-    h.wakeA = wake; h.wakeB = wake + (size_t)g.TX * g.TY * nframes;
+    h.wakeA = wake; h.wakeB = wake + (size_t)g.TX * g.TY * (wake_frames > 0 ? wake_frames : nframes);
     h.rounds_out = rounds; h.status = status; h.only_frames = only_frames;
     h.ra = RingArgs{ring_words, nring_words, ring_code, ring_code ? redo : nullptr};
     h.fs = fs ? *fs : FrameSet{};

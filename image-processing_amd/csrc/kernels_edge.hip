@@ -448,11 +448,11 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, bool blur, Geo g, int nframes, int low,
                   int high, uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                   hipStream_t st, const GateDev *gate, const int *tab, uint8_t *gate_gray, uint8_t *rowflags, bool dec3,
-                  int rows_per_unit, const FrontSplit *split, const FrameSet *fs, const uint8_t *const *src_parts) {
+                  int rows_per_unit, const FrontSplit *split, const FrameSet *fs, const uint8_t *const *src_parts, const HystLaunch *lead) {
     static const char *force_tiled = getenv("LANECV_FRONT_TILED");       // diagnostics: use the tiled kernel everywhere
     if (in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1')) {
         launch_front_stream(src, code, blur, g, nframes, low, high, planeS, planeW, wake, gray_out, blur_out,
-                            rows_per_unit, gate, tab, st, rowflags, dec3, split, fs, src_parts);
+                            rows_per_unit, gate, tab, st, rowflags, dec3, split, fs, src_parts, lead);
         return;
     }
     // (the tiled kernel knows no frame sets: its callers launch it over one part's frames, all of them)
@@ -473,8 +473,8 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st, int *status, const int *only_frames, const uint32_t *ring_words, int nring_words,
-                       const uint64_t *ring_code, int *redo, const FrameSet *fs) {
-    const HystArgs h = hysteresis_args(g, nframes, planeS, planeW, wake, rounds, status, only_frames, ring_words, nring_words, ring_code, redo, fs);
+                       const uint64_t *ring_code, int *redo, const FrameSet *fs, int wake_frames) {
+    const HystArgs h = hysteresis_args(g, nframes, planeS, planeW, wake, rounds, status, only_frames, ring_words, nring_words, ring_code, redo, fs, wake_frames);
     hipLaunchKernelGGL(k_hysteresis, dim3(only_frames ? std::min(nframes, 8) : nframes), dim3(HC_THREADS), 0, st, h);
 }
 

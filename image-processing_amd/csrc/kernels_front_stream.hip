@@ -38,6 +38,7 @@
 // Requires W % 4 == 0 (lanes are then wholly inside or wholly outside the image); other widths and
 // gray input take the tiled kernel in kernels_edge.hip.
 #include "gate.h"
+#include "hysteresis.h"
 #include <type_traits>
 #include <cstdlib>
 #include <algorithm>
@@ -161,6 +162,11 @@ struct FrontArgs {
     int wg_chunk;            // logical workgroups per XCD (see the kernel)
     const int *gate_tab;     // GATE only: the gate's tables in device memory (gate_tables_host)
     GateDev gate;
+    // k_front_lead only: the first lead_blocks workgroups run the hysteresis of another batch (HystLaunch in common.h),
+    // one frame each; the units follow behind them
+    int lead_blocks;
+    HystArgs lead;
+    uint32_t *lead_px;
 };
 
 struct Pair { uint32_t e, o; };   // 4 packed 16-bit values of a lane: e = (px0, px2), o = (px1, px3)
@@ -510,7 +516,8 @@ __device__ __forceinline__ void front_stream_body(const FrontArgs &a) {
     // Workgroups go round-robin over the 8 XCDs, each with its own L2.  Neighbouring strips share the cache lines
     // their rows meet in (a strip row is 744 bytes, not a multiple of 128) and the plane bytes they write, so
     // consecutive units are handed to ONE XCD: workgroup b works on logical workgroup (b % 8) * chunk + b / 8.
-    const int wgl = (int)(blockIdx.x & 7u) * a.wg_chunk + (int)(blockIdx.x >> 3);
+    const unsigned bid = blockIdx.x - (unsigned)a.lead_blocks;
+    const int wgl = (int)(bid & 7u) * a.wg_chunk + (int)(bid >> 3);
     const int u = __builtin_amdgcn_readfirstlane(wgl * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // wave-uniform
     if (u >= a.nunits) return;
     const int per_frame = a.unit_list ? a.nlist : a.nstrips * a.nseg;
@@ -560,6 +567,23 @@ template <bool BLUR, int GATE, bool INTER, bool DEC3 = false>
 __global__ __launch_bounds__(256) void k_front_stream(FrontArgs a) { front_stream_body<BLUR, GATE, INTER, DEC3>(a); }
 template <bool BLUR, int GATE, bool DEC3>
 __global__ __launch_bounds__(256) void k_front_again(FrontArgs a) { front_stream_body<BLUR, GATE, false, DEC3>(a); }
+// The front kernel with the hysteresis of the batch before as its first workgroups (LEAD_THREADS threads each, a frame
+// each): those start at once and run beside the units, instead of a hysteresis kernel between two front kernels -- which is
+// latency-bound, leaves most of the GPU idle, and cannot run beside a front kernel as a launch of its own (its large
+// workgroups find no room while the front kernel's small ones keep arriving).  The ring check's pixel list lives in
+// device memory here: the kernel's LDS (two words and the workgroup reduction's scratch) is charged to every
+// workgroup of the launch, and beside HoughLinesP workgroups a CU has only a few KiB left.
+constexpr int LEAD_THREADS = 128;
+template <bool BLUR, int GATE, bool DEC3>
+__global__ __launch_bounds__(LEAD_THREADS) void k_front_lead(FrontArgs a) {
+    if ((int)blockIdx.x < a.lead_blocks) {
+        __shared__ int any, count;
+        const int f = (int)blockIdx.x;
+        hysteresis_one_frame<LEAD_THREADS, true>(a.lead, f, any, count, a.lead_px + (size_t)f * RING_LIST);
+        return;
+    }
+    front_stream_body<BLUR, GATE, false, DEC3>(a);
+}
 
 // clears, for the flagged frames, the plane rows above row_split that a full pass stored (FrontSplit mode 2)
 template <bool BLUR>
@@ -585,6 +609,10 @@ __global__ __launch_bounds__(256) void k_front_clear(FrontArgs a) {
 }  // namespace
 
 bool front_stream_supported(Geo g) { return g.W % 4 == 0 && g.W >= 8; }
+bool front_takes_lead(Geo g, int in_kind) {
+    static const char *force_tiled = getenv("LANECV_FRONT_TILED");
+    return in_kind == 1 && front_stream_supported(g) && !(force_tiled && force_tiled[0] == '1');
+}
 int front_stream_strips(Geo g) { return (TILE * g.TX + STRIP - 1) / STRIP; }
 
 // rows per unit of the streaming kernel for batches of up to `max_batch` frames: enough units to load every CU many
@@ -622,8 +650,11 @@ FrontGrid front_stream_grid(Geo g, int rows_per_unit, int row_split) {
 void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nframes, int low, int high,
                          uint64_t *planeS, uint64_t *planeW, uint32_t *wake, uint8_t *gray_out, uint8_t *blur_out,
                          int rows_per_unit, const GateDev *gate, const int *tab, hipStream_t st, uint8_t *rowflags, bool dec3,
-                         const FrontSplit *split, const FrameSet *fs, const uint8_t *const *src_parts) {
+                         const FrontSplit *split, const FrameSet *fs, const uint8_t *const *src_parts, const HystLaunch *lead) {
     FrontArgs a;
+    a.lead_blocks = 0;
+    a.lead = HystArgs{};
+    a.lead_px = nullptr;
     a.fs = fs ? *fs : FrameSet{};
     for (int j = 0; j < MAX_PARTS; j++) a.src[j] = (fs && src_parts) ? src_parts[j] : src;
     a.wake = wake;
@@ -662,10 +693,25 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     static const char *wv_env = getenv("LANECV_FRONT_WAVES");
     int wpg = 1;
     if (wv_env && wv_env[0] >= '1' && wv_env[0] <= '4') wpg = wv_env[0] - '0';
+    const bool inter = gray_out || blur_out;
+    const bool with_lead = lead && !inter && !a.clear_top && !a.only_frames;
+    if (with_lead) wpg = LEAD_THREADS / 64;
     const int nwg = (a.nunits + wpg - 1) / wpg;
     a.wg_chunk = (nwg + 7) / 8;
     dim3 grid(8 * a.wg_chunk), block(64 * wpg);
-    const bool inter = gray_out || blur_out;
+    if (with_lead) {
+        a.lead = hysteresis_args(lead->g, lead->nframes, lead->planeS, lead->planeW, lead->wake, lead->rounds, lead->status, nullptr,
+                                 lead->ring_words, lead->nring_words, lead->ring_code, lead->redo, &lead->fs, lead->wake_frames);
+        a.lead_blocks = lead->nframes;
+        a.lead_px = lead->px_scratch;
+        grid = dim3(8 * a.wg_chunk + a.lead_blocks);
+#define LC_FL(B, G, D) hipLaunchKernelGGL((k_front_lead<B, G, D>), grid, block, 0, st, a)
+        if (dec3) { if (blur) LC_FL(true, 0, true); else LC_FL(false, 0, true); }
+        else if (gate) { if (blur) LC_FL(true, 1, false); else LC_FL(false, 1, false); }
+        else { if (blur) LC_FL(true, 0, false); else LC_FL(false, 0, false); }
+#undef LC_FL
+        return;
+    }
     if (a.clear_top) {
         if (!a.only_frames || !a.rowflags) return;
         if (blur) hipLaunchKernelGGL((k_front_clear<true>), grid, block, 0, st, a);

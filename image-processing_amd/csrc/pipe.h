@@ -22,6 +22,7 @@ struct Slot {
     bool timed = false;               // the launch that covers it recorded the stage events
     bool fast_lines = false;          // its HoughLinesP ran in the LDS-resident kernel, which may leave frames to the general one
     int level = 0;                    // ROI-scheme level of the launch that covers it; the pipeline's nlevels = classified in full
+    bool tail_queued = true;          // what follows hysteresis is queued (false while its launch's hysteresis waits to lead the next front launch)
     hipEvent_t done = nullptr;        // fires when the launch that covers the slot has finished
     // its part of the bank's pinned result block
     int *h_rounds = nullptr, *h_status = nullptr, *h_segcount = nullptr;
@@ -41,6 +42,26 @@ struct Bank {
     int planes_level = 0;             // loosest level a launch of this bank ran at since its planes were last cleared down
     int32_t *h_res = nullptr;         // pinned host mirror of the result block: [segcount][rounds][status 8 * parts][segments]
     bool zero_copy = false;           // the kernels write the result block straight into h_res (mapped pinned memory)
+};
+
+// One launch of a bank: which of its slots take part, and over how many of the bank's frames the kernels are launched
+// (from frame 0 up to the last frame of the last slot taking part; the frame set makes them skip the rest).
+struct Launch {
+    lanecv::FrameSet fs{};
+    const uint8_t *src[lanecv::MAX_PARTS] = {};
+    int nframes = 0;
+    int level = 0;
+};
+
+// A launch whose front kernel is queued and whose hysteresis is not yet: it will lead the next front launch (or, if the
+// launch's slots are waited for first, run as a kernel of its own), and everything behind it follows then.
+struct PendingTail {
+    bool active = false;
+    int bank = 0;
+    Launch L;
+    hipStream_t ls = nullptr;         // the launch's tail stream
+    bool skipping = false, eager = false, fused_resize = false;
+    size_t src_bytes = 0;
 };
 
 struct lc_pipe {
@@ -90,6 +111,11 @@ struct lc_pipe {
     // streams' HoughLinesP kernels run on, and a third launch fills the CUs the slowest frames of the first leave idle.
     bool tail_streams = false;
     bool hyst_on_edge = false;    // with tail streams: hysteresis stays on the edge stream, behind its front kernel
+    // ... and, for launches the streaming front kernel takes, not as a kernel of its own but as the first workgroups of the
+    // NEXT front launch (k_front_lead): the edge stream then holds front kernels only, back to back.  The tail of a launch
+    // is therefore queued one submit later (or when its slots are waited for): `pend`.
+    bool hyst_fused = false;
+    PendingTail pend;
     // The streaming front kernel's unit height (fixed for the pipeline's largest batch: its change tracking is per unit)
     // and, for pipelines with an ROI, which units it classifies at all.  The final edge map is the hysteresis result
     // INSIDE the ROI, and that depends on pixels outside it only through weak pixels that connect the two.  The front

@@ -285,6 +285,13 @@ int setup_streams(lc_pipe *pp) {
         const bool long_front = pp->parts > 1 || classified >= 64ll << 20;
         pp->tail_streams = own_lines && pp->banks.size() >= 3 && (ts ? ts[0] != '0' : long_front);
         pp->hyst_on_edge = pp->tail_streams && !(ts && ts[0] == '1');
+        // LANECV_HYST_LEAD=1: hysteresis not as a kernel of its own on the edge stream but as the first workgroups of the
+        // next front launch (lc_pipe::hyst_fused).  Off by default: the edge stream then holds front kernels only (0.33 ms
+        // a batch at 1080p x 256 instead of 0.29 + 0.11), but beside front kernels that never pause the HoughLinesP
+        // kernels take 1.2 ms instead of 1.06, the tail streams become the limit, and a batch's tail starts a submit
+        // later: 0.49 ms a batch against 0.445.
+        const char *hl = getenv("LANECV_HYST_LEAD");
+        pp->hyst_fused = pp->hyst_on_edge && front_takes_lead(pp->g, 1) && !p.keep_intermediates && hl && hl[0] == '1';
         if (pp->tail_streams) pp->st_post = pp->st_lines;
         else if (pp->banks.size() > 1 && !(po && po[0] == '0')) {
             hipStream_t st = picker.pick(mine, &own);

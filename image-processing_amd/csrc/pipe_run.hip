@@ -15,15 +15,6 @@ inline void stamp(lc_pipe *pp, Bank &bk, int ev, hipStream_t st) {
 
 bool vote_is_fused(const lc_pipe *pp) { return pp->p.want_accumulator && pp->p.want_segments && pp->fuse_vote; }
 
-// One launch of a bank: which of its slots take part, and over how many of the bank's frames the kernels are launched
-// (from frame 0 up to the last frame of the last slot taking part; the frame set makes them skip the rest).
-struct Launch {
-    FrameSet fs{};
-    const uint8_t *src[MAX_PARTS] = {};
-    int nframes = 0;
-    int level = 0;
-};
-
 // What follows hysteresis on stream es: the masked edge map, the ordered point list and, for recipes that want the
 // accumulator without segments (or with LANECV_VOTE_FUSED=0), the vote kernel.
 void enqueue_post(lc_pipe *pp, Bank &bk, const Launch &L, hipStream_t es) {
@@ -121,6 +112,74 @@ hipStream_t next_lines_stream(lc_pipe *pp) {
     return turn ? pp->st_lines_more[turn - 1] : pp->st_lines;
 }
 
+// the hysteresis of a launch as the arguments a front launch carries (see HystLaunch)
+HystLaunch hyst_launch(lc_pipe *pp, const PendingTail &T) {
+    Bank &bk = pp->banks[T.bank];
+    Work &w = bk.w;
+    const lc_pipe::SkipLevel *SL = T.skipping ? &pp->levels[T.L.level] : nullptr;
+    HystLaunch h{};
+    h.g = w.g; h.nframes = T.L.nframes;
+    h.planeS = w.planeS.p; h.planeW = w.planeW.p; h.wake = w.wake.p;
+    h.rounds = w.r_rounds; h.status = w.r_status;
+    h.ring_words = SL ? SL->ring_words.p : nullptr; h.nring_words = SL ? SL->n_ring_words : 0;
+    h.ring_code = SL ? SL->ring_code.p : nullptr;
+    h.redo = w.redo.p;
+    h.px_scratch = w.ring_px.p;
+    h.fs = T.L.fs;
+    h.wake_frames = w.B;
+    return h;
+}
+
+// Everything of the pending launch (pp->pend) behind its front kernel: hysteresis -- unless the front launch just queued
+// carried it (hysteresis_led) --, the second pass over flagged frames while such frames are about, finalize, point
+// lists, HoughLinesP and the events that mark its slots done.
+int finish_tail(lc_pipe *pp, bool hysteresis_led) {
+    PendingTail T = pp->pend;
+    pp->pend.active = false;
+    if (!T.active) return LC_OK;
+    Bank &bk = pp->banks[T.bank];
+    Work &w = bk.w;
+    const lc_pipe_params &p = pp->p;
+    Slot *first = &pp->slots[(size_t)T.bank * pp->parts];
+    const Launch &L = T.L;
+    const int n = L.nframes;
+    hipStream_t es = pp->st_edge, ps = pp->st_post, ls = T.ls;
+    if (pp->tail_streams) ps = ls;            // the launch's short kernels share its HoughLinesP stream
+    // hysteresis runs on hs: the post (or tail) stream, or the edge stream itself (behind its front kernel, before the next)
+    hipStream_t hs = pp->hyst_on_edge ? es : ps;
+    if (hs != es) HIP_TRY(hipStreamWaitEvent(hs, bk.ev[EV_FRONT], 0));
+    // Hysteresis; with an ROI level active the frame's workgroup then proves that the units classified settle the ROI's
+    // edges, or flags the frame (rare).  Flagged frames: all units again, and their hysteresis -- two launches that
+    // leave at once for the other frames, queued only while flagged frames are about (lc_pipe::redo_hold).  (What the full
+    // passes leave in the plane rows of units the level does not classify is cleared before the bank's next launch:
+    // lc_pipe_wait sees the flag.)
+    if (!hysteresis_led) {
+        const lc_pipe::SkipLevel *SL = T.skipping ? &pp->levels[L.level] : nullptr;
+        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, hs, w.r_status, nullptr, SL ? SL->ring_words.p : nullptr,
+                          SL ? SL->n_ring_words : 0, SL ? SL->ring_code.p : nullptr, w.redo.p, &L.fs, w.B);
+    }
+    if (T.skipping && T.eager) {
+        const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
+        launch_front(L.src[0], T.src_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
+                     nullptr, nullptr, hs, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, T.fused_resize,
+                     pp->front_rows, &again, &L.fs, L.src);
+        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, hs, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs, w.B);
+    }
+    if (hs != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_HYST], hs));
+    if (hs != ps) HIP_TRY(hipStreamWaitEvent(ps, bk.ev[EV_HYST], 0));
+    enqueue_post(pp, bk, L, ps);
+    const int ready = (p.want_accumulator && !vote_is_fused(pp)) ? EV_VOTE : EV_POINTS;
+    if (ls != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[ready], ps));
+    if (pp->timing && ready == EV_POINTS && !vote_is_fused(pp)) (void)hipEventRecord(bk.ev[EV_VOTE], ps);
+    // (a stand-alone vote kernel reads the point list the general HoughLinesP kernel permutes: HoughLinesP behind it, then)
+    if (ls != ps) HIP_TRY(hipStreamWaitEvent(ls, bk.ev[ready], 0));
+    enqueue_lines(pp, bk, first, L, ls);
+    HIP_TRY(hipGetLastError());
+    for (int j = 0; j < bk.parts; j++)
+        if (L.fs.count[j]) first[j].tail_queued = true;
+    return LC_OK;
+}
+
 // Queues the kernels for the bank's pending slots: one launch each over all their frames.
 int launch_bank(lc_pipe *pp, int bi) {
     Bank &bk = pp->banks[bi];
@@ -141,9 +200,8 @@ int launch_bank(lc_pipe *pp, int bi) {
     }
     if (L.nframes == 0) return LC_OK;
     const int n = L.nframes;
-    hipStream_t es = pp->st_edge, ps = pp->st_post;
-    hipStream_t ls = next_lines_stream(pp);
-    if (pp->tail_streams) ps = ls;            // the launch's short kernels share its HoughLinesP stream
+    hipStream_t es = pp->st_edge;
+    hipStream_t ls = next_lines_stream(pp);   // the launch's HoughLinesP stream (with tail streams: of its short kernels too)
     if (pp->level > 0 && pp->nlevels > 0) {
         if (pp->level_hold > 0) pp->level_hold--;
         else { pp->level--; pp->level_hold = 0; }     // try one level in again
@@ -200,46 +258,34 @@ int launch_bank(lc_pipe *pp, int bi) {
         }
         bk.planes_level = L.level;
     }
+    // The front kernel -- with the hysteresis of the launch before as its first workgroups, if that is still to come
+    HystLaunch lead{};
+    const bool with_lead = pp->pend.active && pp->hyst_fused && !w.inter;
+    if (with_lead) lead = hyst_launch(pp, pp->pend);
     launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p,
                  w.wake.p, w.inter ? w.gray.p : nullptr, (w.inter && p.blur) ? w.blur.p : nullptr, es,
                  pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize, pp->front_rows,
-                 pp->nlevels > 0 ? &skip : nullptr, &L.fs, L.src);
-    // hysteresis runs on hs: the post (or tail) stream, or the edge stream itself (behind its front kernel, before the next)
-    hipStream_t hs = pp->hyst_on_edge ? es : ps;
-    if (hs != es || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_FRONT], es));
-    if (hs != es) HIP_TRY(hipStreamWaitEvent(hs, bk.ev[EV_FRONT], 0));
-    // Hysteresis; with an ROI level active the frame's workgroup then proves that the units classified settle the ROI's
-    // edges, or flags the frame (rare).  Flagged frames: all units again, and their hysteresis -- two launches that
-    // leave at once for the other frames, which is nearly always all of them.  (What the full passes leave in the plane
-    // rows of units the level does not classify is cleared before the bank's next launch: lc_pipe_wait sees the flag.)
-    const lc_pipe::SkipLevel *SL = skipping ? &pp->levels[L.level] : nullptr;
-    launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, hs, w.r_status, nullptr, SL ? SL->ring_words.p : nullptr,
-                      SL ? SL->n_ring_words : 0, SL ? SL->ring_code.p : nullptr, w.redo.p, &L.fs);
-    if (skipping && eager) {
-        const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
-        launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
-                     nullptr, nullptr, hs, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, fused_resize,
-                     pp->front_rows, &again, &L.fs, L.src);
-        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, hs, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs);
+                 pp->nlevels > 0 ? &skip : nullptr, &L.fs, L.src, with_lead ? &lead : nullptr);
+    if (pp->pend.active) {
+        int rc;
+        if ((rc = finish_tail(pp, with_lead))) return rc;
     }
-    if (hs != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_HYST], hs));
-    if (hs != ps) HIP_TRY(hipStreamWaitEvent(ps, bk.ev[EV_HYST], 0));
-    enqueue_post(pp, bk, L, ps);
-    const int ready = (p.want_accumulator && !vote_is_fused(pp)) ? EV_VOTE : EV_POINTS;
-    if (ls != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[ready], ps));
-    if (pp->timing && ready == EV_POINTS && !vote_is_fused(pp)) (void)hipEventRecord(bk.ev[EV_VOTE], ps);
-    // (a stand-alone vote kernel reads the point list the general HoughLinesP kernel permutes: HoughLinesP behind it, then)
-    if (ls != ps) HIP_TRY(hipStreamWaitEvent(ls, bk.ev[ready], 0));
-    enqueue_lines(pp, bk, first, L, ls);
-    HIP_TRY(hipGetLastError());
+    PendingTail T;
+    T.active = true; T.bank = bi; T.L = L; T.ls = ls; T.skipping = skipping; T.eager = eager; T.fused_resize = fused_resize; T.src_bytes = src_bytes;
+    if (!pp->hyst_on_edge || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_FRONT], es));     // (what a hysteresis kernel on another stream waits for)
     for (int j = 0; j < bk.parts; j++) {
         if (!L.fs.count[j]) continue;
         first[j].pending = false;
         first[j].level = L.level;
         first[j].timed = pp->timing;
         first[j].eager_redo = eager;
+        first[j].tail_queued = false;
     }
-    return LC_OK;
+    pp->pend = T;
+    // Launches whose hysteresis can lead the next front launch leave their tail for then (or for lc_pipe_wait); the
+    // others queue it now
+    if (pp->hyst_fused && !w.inter) return LC_OK;
+    return finish_tail(pp, false);
 }
 
 // The copy stream, created by the first host submit (a pipeline fed device frames never owns it).  Copies run on the
@@ -355,7 +401,7 @@ int enqueue_repair(lc_pipe *pp, Slot &s) {
     launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, L.nframes, pp->low, pp->high,
                  w.planeS.p, w.planeW.p, w.wake.p, nullptr, nullptr, ps, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p,
                  w.rowflags.p, pp->fused_dec3(), pp->front_rows, &again, &L.fs, L.src);
-    launch_hysteresis(w.g, L.nframes, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs);
+    launch_hysteresis(w.g, L.nframes, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, ps, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs, w.B);
     enqueue_post(pp, bk, L, ps);
     enqueue_lines(pp, bk, first, L, ps);
     HIP_TRY(hipGetLastError());
@@ -367,6 +413,7 @@ int enqueue_repair(lc_pipe *pp, Slot &s) {
 namespace lanecv {
 void pipe_flush_pending(lc_pipe *pipe) {
     for (size_t b = 0; b < pipe->banks.size(); b++) (void)launch_bank(pipe, (int)b);
+    (void)finish_tail(pipe, false);
 }
 }  // namespace lanecv
 
@@ -414,6 +461,7 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     if (!s->busy) return fail(LC_EINVAL, "slot %d has nothing in flight", slot);
     const lc_pipe_params &p = pipe->p;
     if (s->pending && (rc = launch_bank(pipe, s->bank))) return rc;      // its bank is not full: what is there goes now
+    if (!s->tail_queued && (rc = finish_tail(pipe, false))) return rc;   // its hysteresis was waiting for a front launch to lead
     if ((rc = wait_event(pipe, slot, s->done))) return rc;
     if (s->level < pipe->nlevels && s->h_status[3]) {
         // Frames the ROI scheme could not settle from the units near the ROI were classified again in full.  Their full

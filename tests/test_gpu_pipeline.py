@@ -541,3 +541,71 @@ def test_rows_follow_when_the_level_moves_out_before_the_launch(oracle, monkeypa
     check(1, b_)
     assert pipe.rows_uploaded(0) == 0 and pipe.roi_skip(0)[1] == w * h
     pipe.close()
+
+
+@pytest.mark.parametrize("layout", [{"LANECV_TAIL_STREAMS": "0"}, {"LANECV_TAIL_STREAMS": "1"}, {"LANECV_TAIL_STREAMS": "2"},
+                                    {"LANECV_TAIL_STREAMS": "2", "LANECV_HYST_LEAD": "1"},
+                                    {"LANECV_TAIL_STREAMS": "2", "LANECV_HYST_LEAD": "1", "LANECV_EAGER_REDO": "1"}],
+                         ids=["post-stream", "tails", "tails+edge-hysteresis", "hysteresis-leads", "hysteresis-leads+eager"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_stream_layouts_agree(oracle, monkeypatch, layout, group):
+    """The same batches through every stream layout of a pipeline with six slots, as banks of one slot and of two (post stream; the short kernels on the
+    HoughLinesP streams; hysteresis on the edge stream; hysteresis as the first workgroups of the next front launch),
+    all slots in flight, device-resident frames, with frames among them that the units near the ROI cannot settle
+    (classified again in the stream once such frames are about, else when the slot is waited for) and a short batch:
+    masked map, accumulator and segments must equal the oracle's whatever the layout, the frames redone be counted,
+    and a slot reused after them be clean."""
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    for k, v in layout.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("LANECV_SKIP_OFF_BATCHES", "0")
+    monkeypatch.setenv("LANECV_GROUP_SIZE", str(group))
+    w, h, nslots = 960, 540, 6
+    rec = Recipe.north_star(w, h)
+    pipe = LanePipeline(w, h, rec, max_batch=6, nslots=nslots, seg_capacity=512)
+    assert pipe.layout()[0] == group
+
+    def faint_edge(x, ytop):
+        g = np.full((h, w), 60, np.int32)
+        g[:ytop, x:] += 120
+        g[ytop:, x:] += 60
+        return np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+
+    road = [synth.synth_road(w, h, seed=77, t=t) for t in range(6)]
+    batches, want_redone = [], []
+    for b in range(3 * nslots):
+        fr = [road[(b + i) % 6] for i in range(6 if b != 5 else 2)]
+        n_bad = 0
+        if b in (2, 3, 7):
+            fr[1] = faint_edge(w // 2 + 40 + 10 * b, 60 + 5 * b)
+            n_bad = 1
+        batches.append(np.stack(fr))
+        want_redone.append(n_bad)
+    ref = {}
+
+    def check(b, slot):
+        segs = pipe.collect(slot)
+        masked, acc = pipe.read(slot, _abi.BUF_MASKED), pipe.read(slot, _abi.BUF_ACC)
+        assert pipe.row_skip(slot)[1] == want_redone[b], b
+        for i, f in enumerate(batches[b]):
+            key = f.tobytes()
+            if key not in ref:
+                ref[key] = _oracle_frame(oracle, f, rec, pipe.roi)
+            r = ref[key]
+            assert (masked[i] == r["masked"]).all(), (b, i)
+            assert (acc[i] == r["acc"]).all(), (b, i)
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (b, i)
+
+    inflight = []
+    for b, fr in enumerate(batches):
+        slot = b % nslots
+        if len(inflight) == nslots:
+            check(*inflight.pop(0))
+        ptr = pipe.upload(slot, fr)
+        pipe.submit_device(slot, ptr, len(fr))
+        inflight.append((b, slot))
+    for ob, oslot in inflight:
+        check(ob, oslot)
+    pipe.close()
