@@ -453,7 +453,7 @@ def main():
         # exclusive run: in the timed region its short kernels sit on a stream of their own and their event-to-event
         # times are mostly waiting for room beside the next batch's front kernel.
         edge_x = em["front"] + em["hyst"] + em["final"]
-        out["roofline_edge_stage"] = {"kernels": "k_front_stream + k_hysteresis + k_finalize_sparse, one batch in flight",
+        out["roofline_edge_stage"] = {"kernels": "k_front_stream + k_hysteresis + k_finalize_roi, one batch in flight",
                                       "algorithmic_bytes_per_launch": stage_bytes, "launch_ms": round(edge_x, 4),
                                       "achieved": round(stage_bytes / (edge_x * 1e-3) / 1e9, 1),
                                       "frac": round(stage_bytes / (edge_x * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
