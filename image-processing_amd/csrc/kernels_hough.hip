@@ -316,6 +316,7 @@ struct VoteLane {
     uint32_t rfix;               // turns the rounded float's bits into (bin - first reachable bin of this angle)
     uint32_t wid;                // reachable bins of this angle - 1
     uint32_t *words;
+    uint32_t kfold;              // rfix + base: turns the rounded float's bits straight into the bin's index in the compact array
 };
 // cvRound of |v| < 2^22: adding 1.5 * 2^23 rounds v half-to-even into the low mantissa bits
 constexpr float ROUND_MAGIC = 12582912.0f;
@@ -330,6 +331,16 @@ __device__ __forceinline__ void vote_bin(const VoteLane &vl, float fj, float fi,
     r = rc;
     const uint32_t a = vl.base + r;
     sh = (a & 1u) << 4;
+    widx = a >> 1;
+}
+
+// The same for a pixel that is known to lie inside the points' bounding box -- a point of the frame -- without the range
+// test: x * c and y * s are each monotone in the coordinate and so are the rounded sum and the rounded bin, so the bin lies
+// between those of the box's corners, which is the range the angle's row was sized for.
+__device__ __forceinline__ void vote_bin_inside(const VoteLane &vl, float fj, float fi, uint32_t &widx, uint32_t &sh) {
+    const float v = __fadd_rn(__fmul_rn(fj, vl.c), __fmul_rn(fi, vl.s));
+    const uint32_t a = __float_as_uint(__fadd_rn(v, ROUND_MAGIC)) + vl.kfold;
+    sh = a << 4;                 // (a shift takes the low five bits: (a & 1) << 4)
     widx = a >> 1;
 }
 
@@ -360,11 +371,12 @@ __device__ __forceinline__ void job_work(Jobs *jb, int part, const VoteLane &vl,
                 int j0, i0, j1, i1;
                 wk.at(t0, k ? -1 : 1, j0, i0);
                 wk.at(t1, k ? -1 : 1, j1, i1);
-                uint32_t w0, s0, w1, s1, over;
-                vote_bin(vl, (float)j0, (float)i0, w0, s0, over);
-                vote_bin(vl, (float)j1, (float)i1, w1, s1, over);
-                atomicSub(&vl.words[w0], vl.one << s0);
-                atomicSub(&vl.words[w1], (two ? vl.one : 0u) << s1);
+                // (the pixels of a walked line whose votes go are edge pixels: points of the frame)
+                uint32_t w0, s0, w1, s1;
+                vote_bin_inside(vl, (float)j0, (float)i0, w0, s0);
+                vote_bin_inside(vl, (float)j1, (float)i1, w1, s1);
+                atomicSub(&vl.words[w0], vl.one << (s0 & 31u));
+                atomicSub(&vl.words[w1], (two ? vl.one : 0u) << (s1 & 31u));
             }
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -937,6 +949,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     vl.rfix = a_rfix[lane];
     vl.wid = a_wid[lane];
     vl.words = reinterpret_cast<uint32_t *>(c.lacc);
+    vl.kfold = vl.rfix + vl.base;
     SETUP_MARK(3);
     if (acc_full != nullptr) {
         uint32_t *fw = vl.words;
@@ -951,23 +964,23 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
             int t = 0;
             for (; t + 4 <= m; t += 4) {
                 float fj[4], fi[4];
-                uint32_t widx[4], sh[4], over;
+                uint32_t widx[4], sh[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     fj[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), t + q));
                     fi[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), t + q));
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) vote_bin(vl, fj[q], fi[q], widx[q], sh[q], over);
+                for (int q = 0; q < 4; q++) vote_bin_inside(vl, fj[q], fi[q], widx[q], sh[q]);
 #pragma unroll
-                for (int q = 0; q < 4; q++) atomicAdd(&fw[widx[q]], vl.one << sh[q]);
+                for (int q = 0; q < 4; q++) atomicAdd(&fw[widx[q]], vl.one << (sh[q] & 31u));
             }
             for (; t < m; t++) {
                 const float fj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fjv), t));
                 const float fi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fiv), t));
-                uint32_t widx, sh, over;
-                vote_bin(vl, fj, fi, widx, sh, over);
-                atomicAdd(&fw[widx], vl.one << sh);
+                uint32_t widx, sh;
+                vote_bin_inside(vl, fj, fi, widx, sh);
+                atomicAdd(&fw[widx], vl.one << (sh & 31u));
             }
         }
         __syncthreads();
