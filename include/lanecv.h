@@ -184,7 +184,9 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
 typedef struct lc_pipe_params {
     int width, height;        /* frame size */
     int max_batch;            /* frames per submit, upper bound */
-    int nslots;               /* independent in-flight batches (each with its own HIP stream) */
+    int nslots;               /* independent in-flight batches.  A pipeline's streams do not grow with it; slots of small
+                                 batches (2 * max_batch <= CUs, four slots or more) share banks of buffers and are
+                                 launched a bank at a time: see lc_pipe_layout */
     int color_code;           /* LC_COLOR_BGR2GRAY or LC_COLOR_RGB2GRAY */
     int blur;                 /* 1: GaussianBlur 5x5 between gray and Canny (F1 recipe) */
     double canny_lo, canny_hi;
@@ -276,19 +278,20 @@ int lc_pipe_hyst_rounds(lc_pipe *pipe, int slot, int *rounds_max, int *rounds_to
  * *pixels_classified = pixels per frame the edge kernel classifies (width x height without an ROI), *frames_redone = frames
  * of the slot's last batch that needed the full pass.  Any pointer may be NULL. */
 int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_classified, int *frames_redone);
-/* Diagnostics with no counterpart in the reference: how many of the pipeline's streams found no hardware queue of
- * their own when it was created (HIP folds a process's streams onto GPU_MAX_HW_QUEUES queues; the pipeline probes
- * which ones share).  0 = every stage overlaps as designed; otherwise stages that were meant to run side by side
- * were put on one stream. */
 /* Diagnostics with no counterpart in the reference: the first row of every frame of the slot's last batch that was
  * copied to the GPU by lc_pipe_submit_host (0: whole frames, also for batches submitted from device memory).  With an
  * ROI the rows above the first one the kernels read are not copied. */
 int lc_pipe_rows_uploaded(lc_pipe *pipe, int slot, int *first_row);
+/* Diagnostics with no counterpart in the reference: how many of the pipeline's streams found no hardware queue of
+ * their own when it was created (HIP folds a process's streams onto GPU_MAX_HW_QUEUES queues; the pipeline probes
+ * which ones share).  0 = every stage overlaps as designed; otherwise stages that were meant to run side by side
+ * were put on one stream. */
 int lc_pipe_shared_queues(lc_pipe *pipe, int *count);
 /* Diagnostics with no counterpart in the reference: how the pipeline laid itself out.  *group_size = consecutive slots
- * whose HoughLinesP runs as ONE launch (1: a launch per slot; more for batches that leave most CUs free, see
- * lc_pipe_create), *lines_streams = streams HoughLinesP launches take in turn, *roi_levels = levels of the ROI scheme
- * (0: every frame is classified in full).  Any pointer may be NULL. */
+ * that share a bank of buffers and ONE launch of every kernel, queued when the bank's last slot is submitted or one of
+ * its slots is waited for (1: a launch per slot; more for batches that leave most CUs free), *lines_streams = streams
+ * HoughLinesP launches take in turn, *roi_levels = levels of the ROI scheme (0: every frame is classified in full).
+ * Any pointer may be NULL. */
 int lc_pipe_layout(lc_pipe *pipe, int *group_size, int *lines_streams, int *roi_levels);
 /* Synchronous copy of nframes host frames into the slot's own input buffer, nothing else:
  * a later lc_pipe_submit_device on that pointer then runs with the input resident in HBM. */
