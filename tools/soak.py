@@ -17,7 +17,8 @@ STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W, H = 1920, 1080
 rec = Recipe.north_star(W, H)
-pipe = LanePipeline(W, H, rec, max_batch=B, nslots=3, seg_capacity=128)
+NS = int(os.environ.get("SOAK_SLOTS", "3"))
+pipe = LanePipeline(W, H, rec, max_batch=B, nslots=NS, seg_capacity=128)
 adv = synth.adversarial_frames(W, H)
 kinds = [np.stack([synth.synth_road(W, H, seed=100, t=t) for t in range(B)]),
          np.stack([synth.synth_road(W, H, seed=7, t=3 * t, shadow=(t % 2 == 0)) if t % 8 else adv["black"] for t in range(B)])]
@@ -51,8 +52,8 @@ def check(step, slot, kind):
 
 
 for step in range(STEPS):
-    slot, kind = step % 3, (step // 2) % 2
-    if len(inflight) == 3:
+    slot, kind = step % NS, (step // 2) % 2
+    if len(inflight) == NS:
         check(*inflight.pop(0))
     pipe.submit_device(slot, dev[kind].data_ptr(), B if step % 7 else max(1, B // 2))
     inflight.append((step, slot, kind if step % 7 else kind + 2))
