@@ -59,6 +59,25 @@ def pmc_traffic(batch):
         return round(json.load(fh)["kernels"]["k_front_stream<true, 0, false, false>"]["traffic_bytes"])
 
 
+def valu_issue(batch, launch_ms, device):
+    """The bound the front kernel actually runs against: vector-instruction issue.  Instructions per launch from the
+    committed PMC pass (SQ_INSTS_VALU), one wave instruction per SIMD every 4 cycles (what the packed 16-bit, v_dot4,
+    v_perm, v_alignbyte and DPP forms the kernel consists of issue at on gfx950: tools/valu_rate.hip), the launch
+    duration measured here."""
+    import torch
+    path = os.path.join(ROOT, "profiles", "round3_pmc_edge_stage.json")
+    if batch != 256 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        insts = json.load(fh)["kernels"]["k_front_stream<true, 0, false, false>"]["SQ_INSTS_VALU"]
+    props = torch.cuda.get_device_properties(device)
+    mhz = (getattr(props, "clock_rate", 0) or 2400000) / 1e3
+    peak = props.multi_processor_count * 4 * mhz * 1e6 / 4 / 1e9            # 1e9 wave instructions per second
+    achieved = insts / (launch_ms * 1e-3) / 1e9
+    return {"bound": "vector issue", "instructions_per_launch": insts, "cycles_per_instruction": 4, "clock_mhz": round(mhz),
+            "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "1e9 wave instructions/s", "frac": round(achieved / peak, 4)}
+
+
 def vote_rates(dev_ptr, batch, device):
     """LDS-atomic throughput of the Hough vote: the same frames through a pipeline that stops at the full-vote
     accumulator (k_vote on every frame; in the timed recipe HoughLinesP's kernel produces the accumulator on the
@@ -462,6 +481,7 @@ def main():
                                      "frac": round(front_bytes / (em["front"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "whole_frame_equivalent_GBs": round(frame_bytes_equiv / (em["front"] * 1e-3) / 1e9, 1),
                                      "stage_ms": {k: round(v, 4) for k, v in em.items()}}
+        out["roofline_exclusive"]["valu_issue"] = valu_issue(batch, em["front"], local_rank)
 
         out["vote"] = vote_rates(ptr, batch, local_rank)
 

@@ -239,6 +239,7 @@ __device__ int g_simd[8];
 __device__ long long g_setup[16];             // frame 0: cycles since kernel start at the marks of the set-up
 #define SETUP_MARK(k) do { if (f == 0 && tid == 0) g_setup[k] = STAMP() - t_kernel0; } while (0)
 __device__ long long g_frame_cycles[1024];   // consumer loop and whole kernel (set-up included) per frame: [2f], [2f + 1]
+__device__ long long g_frame_real[512];      // whole kernel per frame in ticks of the constant 100 MHz counter (s_memrealtime)
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
 #ifndef LC_STAMPS
@@ -264,22 +265,29 @@ struct Ppht {
     // fast path: the frame's edge bits live in LDS, only the 64-pixel words that hold a point
     const AngleEntry *ltab;    // LDS copy of tab (walk steps of every angle)
     uint64_t *lmask;           // those words, row after row
-    const uint4 *rowtab;       // per row ymin + r: x = LDS index of the row's first word, (z, w) = which of the row's 64 words are kept
+    // The row table: per row ymin + r one entry (frames up to 2048 pixels wide: wshift = 0) or two (wider ones, 32 image
+    // words each: wshift = 1) -- x = LDS index of the first kept word the entry covers, y = which of its 32 words are kept
+    const uint2 *rowtab;
+    int wshift;
     int ymin, nrows;
 };
 
-// LDS word of image word wi of a row-table entry; false if that word holds no point (all zero)
-__device__ __forceinline__ bool row_word(const uint4 &e, int wi, uint32_t &widx) {
-    const uint64_t bm = (uint64_t)e.z | ((uint64_t)e.w << 32);
-    widx = e.x + (uint32_t)__popcll(bm & ((1ull << wi) - 1));
-    return (bm >> wi) & 1;
+// the entry of row ymin + r that covers image word wi
+__device__ __forceinline__ uint32_t row_slot(const Ppht &c, uint32_t r, int wi) {
+    return (r << c.wshift) + (((uint32_t)wi >> 5) & (uint32_t)c.wshift);
+}
+// LDS word of image word wi of its row-table entry; false if that word holds no point (all zero)
+__device__ __forceinline__ bool row_word(const uint2 &e, int wi, uint32_t &widx) {
+    const uint32_t b = (uint32_t)wi & 31u;
+    widx = e.x + (uint32_t)__popc(e.y & ((1u << b) - 1u));
+    return (e.y >> b) & 1u;
 }
 
 // Edge bit of pixel (j, i) in the LDS copy; widx is the LDS word that holds it (valid when the result is true).
 __device__ __forceinline__ bool lds_mask_bit(const Ppht &c, int j, int i, uint32_t &widx) {
     const unsigned r = (unsigned)(i - c.ymin);
     if (r >= (unsigned)c.nrows) return false;
-    const uint4 e = c.rowtab[r];
+    const uint2 e = c.rowtab[row_slot(c, r, j >> 6)];
     if (!row_word(e, j >> 6, widx)) return false;
     return (c.lmask[widx] >> (j & 63)) & 1;
 }
@@ -334,9 +342,9 @@ __device__ __forceinline__ void vote_bin(const VoteLane &vl, float fj, float fi,
     widx = a >> 1;
 }
 
-// The same for a pixel that is known to lie inside the points' bounding box -- a point of the frame -- without the range
-// test: x * c and y * s are each monotone in the coordinate and so are the rounded sum and the rounded bin, so the bin lies
-// between those of the box's corners, which is the range the angle's row was sized for.
+// The same for a point of the frame, without the range test: the point lies in the box of its band of rows, x * c and
+// y * s are each monotone in the coordinate and so are the rounded sum and the rounded bin, so the bin lies between those of
+// that box's corners, which the range the angle's row was sized for includes (see the set-up of k_ppht_fast).
 __device__ __forceinline__ void vote_bin_inside(const VoteLane &vl, float fj, float fi, uint32_t &widx, uint32_t &sh) {
     const float v = __fadd_rn(__fmul_rn(fj, vl.c), __fmul_rn(fi, vl.s));
     const uint32_t a = __float_as_uint(__fadd_rn(v, ROUND_MAGIC)) + vl.kfold;
@@ -419,7 +427,7 @@ __device__ __forceinline__ void fetch_chunks(const Ppht &c, const Walk &wk, int 
     bool inb[2][N];
     int sh[2][N];
     if constexpr (LDS_STATE) {
-        uint4 ent[2][N];
+        uint2 ent[2][N];
         int wcol[2][N];
 #pragma unroll
         for (int k = 0; k < 2; k++)
@@ -431,7 +439,7 @@ __device__ __forceinline__ void fetch_chunks(const Ppht &c, const Walk &wk, int 
                 sh[k][q] = j1 & 63;
                 wcol[k][q] = j1 >> 6;
                 const unsigned r = (unsigned)(i1 - c.ymin);
-                ent[k][q] = c.rowtab[r < (unsigned)c.nrows ? r : 0u];
+                ent[k][q] = c.rowtab[row_slot(c, r < (unsigned)c.nrows ? r : 0u, wcol[k][q] & 63)];
                 if (r >= (unsigned)c.nrows) wcol[k][q] = -1;          // no points in that row
             }
 #pragma unroll
@@ -786,7 +794,12 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     extern __shared__ __align__(16) uint32_t lds32[];
     __shared__ int progress;
     __shared__ Jobs jobs;
-    __shared__ int s_xmin, s_xmax, s_maskwords, s_accbins;
+    __shared__ int s_maskwords, s_accbins;
+    // column range of the points in every band of 2^bshift rows (at most PPHT_BANDS bands), and from those the extreme
+    // bins of every angle: what sizes the angle's row of the compact accumulator
+    constexpr int PPHT_BANDS = 64;
+    __shared__ int b_lo[PPHT_BANDS], b_hi[PPHT_BANDS];
+    __shared__ int a_lo[64], a_hi[64];
     __shared__ int s_part[PPHT_THREADS];
     __shared__ uint32_t a_base[64], a_rfix[64], a_wid[64];
     __shared__ int a_rmin[64];
@@ -799,6 +812,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
 #ifdef LC_STAMPS
     if (f == 0 && lane == 0) g_simd[wave] = __builtin_amdgcn_s_getreg(2308);
     const long long t_kernel0 = STAMP();
+    const long long t_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
     if (only_flagged && !(fallback[f] & 1)) return;   // second launch (more LDS per frame): the frames the first one left
@@ -828,59 +842,57 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     c.seg = seg_all + (size_t)f * seg_cap * 4;
 
     // ---- set-up: everything the loop touches moves into LDS ------------------------------------
-    // layout: [points n][row table nrows x 16 B][accumulator][full-vote accumulator][mask words]
-    // The points arrive sorted by row, then column.  Only bins a pixel of the points' bounding box can
-    // reach are kept of every angle's accumulator row, and of the mask only the 64-pixel words that hold
-    // a point (a 64-bit map per row says which) -- together a fraction of the full arrays.
+    // layout: [points n][row table, 8 B an entry][accumulator (first the full vote, then HoughLinesP's own)][mask words]
+    // The points arrive sorted by row, then column.  Of every angle's accumulator row only the bins are kept that a
+    // pixel of the boxes around the points of each band of rows can reach (bands of 2^bshift rows: the points' bounding
+    // box cut into at most 64 slices, which follows a triangle of lane markings far more closely than the one box does),
+    // and of the mask only the 64-pixel words that hold a point (a 64-bit map per row says which) -- together a
+    // fraction of the full arrays.
     uint32_t *lnz = lds32;
     const int ymin = (int)(nz[0] >> 16), ymax = (int)(nz[n - 1] >> 16);
     const int nrows = ymax - ymin + 1;
     const size_t rt_off = ((size_t)n + 3) & ~(size_t)3;          // 16-byte aligned
     uint32_t *rowtab = lds32 + rt_off;
-    if ((rt_off + 4 * (size_t)nrows) * 4 > (size_t)lds_bytes) {  // (the row table alone does not fit)
+    const int wshift = g.TX > 32 ? 1 : 0;
+    const int nent = nrows << wshift;                            // row-table entries, two words each
+    const size_t rt_words = ((size_t)2 * nent + 3) & ~(size_t)3;
+    if ((rt_off + rt_words) * 4 > (size_t)lds_bytes) {           // (the row table alone does not fit)
         if (tid == 0) { fallback[f] = 3; status[2] = 1; status[4] = 1; }
         return;
     }
     if (tid == 0) {
         progress = 0;
         jobs.seq = 0; jobs.done = 0;
-        s_xmin = INT_MAX; s_xmax = 0;
     }
-    for (int r = tid; r < 4 * nrows; r += PPHT_THREADS) rowtab[r] = 0;
+    if (tid < PPHT_BANDS) { b_lo[tid] = INT_MAX; b_hi[tid] = -1; }
+    if (tid < 64) { a_lo[tid] = INT_MAX; a_hi[tid] = INT_MIN; }
+    int bshift = 0;
+    while (((nrows - 1) >> bshift) >= PPHT_BANDS) bshift++;
+    for (int r = tid; r < 2 * nent; r += PPHT_THREADS) rowtab[r] = 0;
     if (tid < numangle) s_tab[tid] = tab[tid];
     __syncthreads();
-    {
-        int xmin = INT_MAX, xmax = 0;
-        for (int i = tid; i < n; i += PPHT_THREADS) {
-            const uint32_t pt = nz[i];
-            lnz[i] = pt;
-            const int x = (int)(pt & 0xFFFF);
-            xmin = min(xmin, x); xmax = max(xmax, x);
-        }
-        // wave-level reduction first: one LDS atomic per wave
-        for (int d = 32; d >= 1; d >>= 1) {
-            xmin = min(xmin, __shfl_xor(xmin, d));
-            xmax = max(xmax, __shfl_xor(xmax, d));
-        }
-        if (lane == 0) { atomicMin(&s_xmin, xmin); atomicMax(&s_xmax, xmax); }
-    }
+    for (int i = tid; i < n; i += PPHT_THREADS) lnz[i] = nz[i];
     __syncthreads();
     SETUP_MARK(0);
     for (int i = tid; i < n; i += PPHT_THREADS) {
-        // the first point of every 64-pixel word marks the word in its row's map
+        // the first point of every 64-pixel word marks the word in its row's map; the first and the last point of a
+        // row (its leftmost and rightmost) widen the column range of the row's band
         const uint32_t pt = lnz[i];
-        const int wi = (int)(pt & 0xFFFF) >> 6, y = (int)(pt >> 16);
-        const uint32_t pv = i ? lnz[i - 1] : 0u;
-        if (i == 0 || (int)(pv >> 16) != y || ((int)(pv & 0xFFFF) >> 6) != wi)
-            atomicOr(&rowtab[4 * (y - ymin) + 2 + (wi >> 5)], 1u << (wi & 31));
+        const int x = (int)(pt & 0xFFFF), wi = x >> 6, y = (int)(pt >> 16);
+        const uint32_t pv = i ? lnz[i - 1] : 0xFFFFFFFFu, nx = i + 1 < n ? lnz[i + 1] : 0xFFFFFFFFu;
+        const bool row_first = (int)(pv >> 16) != y;
+        if (row_first || ((int)(pv & 0xFFFF) >> 6) != wi)
+            atomicOr(&rowtab[2 * ((((uint32_t)(y - ymin)) << wshift) + ((uint32_t)(wi >> 5) & (uint32_t)wshift)) + 1], 1u << (wi & 31));
+        if (row_first) atomicMin(&b_lo[(y - ymin) >> bshift], x);
+        if ((int)(nx >> 16) != y) atomicMax(&b_hi[(y - ymin) >> bshift], x);
     }
     __syncthreads();
     SETUP_MARK(1);
     {   // exclusive scan of the kept-word counts over the rows -> LDS index of every row's first word
-        const int per = (nrows + PPHT_THREADS - 1) / PPHT_THREADS;
-        const int r0 = tid * per, r1 = min(nrows, r0 + per);
+        const int per = (nent + PPHT_THREADS - 1) / PPHT_THREADS;
+        const int r0 = tid * per, r1 = min(nent, r0 + per);
         int sum = 0;
-        for (int r = r0; r < r1; r++) sum += __popc(rowtab[4 * r + 2]) + __popc(rowtab[4 * r + 3]);
+        for (int r = r0; r < r1; r++) sum += __popc(rowtab[2 * r + 1]);
         s_part[tid] = sum;
         __syncthreads();
         for (int d = 1; d < PPHT_THREADS; d <<= 1) {
@@ -891,22 +903,36 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         }
         int off = s_part[tid] - sum;
         for (int r = r0; r < r1; r++) {
-            rowtab[4 * r] = (uint32_t)off;
-            off += __popc(rowtab[4 * r + 2]) + __popc(rowtab[4 * r + 3]);
+            rowtab[2 * r] = (uint32_t)off;
+            off += __popc(rowtab[2 * r + 1]);
         }
         if (tid == PPHT_THREADS - 1) s_maskwords = s_part[tid];
     }
     SETUP_MARK(2);
-    if (wave == 0) {   // reachable bins of every angle: the extremes are at the corners of the bounding box
-        const int xmin = s_xmin, xmax = s_xmax;
+    {   // Reachable bins of every angle (one per lane): x * c and y * s are each monotone in the coordinate and so are the
+        // rounded sum and the rounded bin, so over a box the extremes are at its corners -- here the boxes of the bands
+        // (the wavefronts share them), each as wide as its points' columns and as high as the band's rows.
         float ac = 0.f, as = 0.f;
         if (lane < numangle) { ac = tab[lane].c; as = tab[lane].s; }
-        auto rbin = [&](int x, int y) {
-            const float v = __fadd_rn(__fmul_rn((float)x, ac), __fmul_rn((float)y, as));
-            return (int)(__float_as_uint(__fadd_rn(v, ROUND_MAGIC)) - 0x4B400000u) + c.half;
-        };
-        const int b0 = rbin(xmin, ymin), b1 = rbin(xmax, ymin), b2 = rbin(xmin, ymax), b3 = rbin(xmax, ymax);
-        const int rmin = min(min(b0, b1), min(b2, b3)), rmax = max(max(b0, b1), max(b2, b3));
+        float vlo = 3.0e38f, vhi = -3.0e38f;
+        for (int b = wave; b < PPHT_BANDS; b += PPHT_WAVES) {
+            const int xl = b_lo[b], xr = b_hi[b];
+            if (xr < 0) continue;                   // (no point in the band)
+            const float y0 = (float)(ymin + (b << bshift)), y1 = (float)min(ymin + ((b + 1) << bshift) - 1, ymax);
+            const float cl = __fmul_rn((float)xl, ac), cr = __fmul_rn((float)xr, ac);
+            const float s0 = __fmul_rn(y0, as), s1 = __fmul_rn(y1, as);
+            const float v0 = __fadd_rn(cl, s0), v1 = __fadd_rn(cr, s0), v2 = __fadd_rn(cl, s1), v3 = __fadd_rn(cr, s1);
+            vlo = fminf(vlo, fminf(fminf(v0, v1), fminf(v2, v3)));
+            vhi = fmaxf(vhi, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+        }
+        if (lane < numangle && vlo <= vhi) {
+            atomicMin(&a_lo[lane], (int)(__float_as_uint(__fadd_rn(vlo, ROUND_MAGIC)) - 0x4B400000u));
+            atomicMax(&a_hi[lane], (int)(__float_as_uint(__fadd_rn(vhi, ROUND_MAGIC)) - 0x4B400000u));
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int rmin = a_lo[lane < numangle ? lane : 0] + c.half, rmax = a_hi[lane < numangle ? lane : 0] + c.half;
         const int nb = lane < numangle ? rmax - rmin + 1 : 0;
         int incl = nb;
         for (int d = 1; d < 64; d <<= 1) {
@@ -923,7 +949,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     }
     __syncthreads();
     const int accbins = s_accbins, maskwords = s_maskwords;
-    const size_t acc_off = rt_off + 4 * (size_t)nrows;                             // in 32-bit words, 16-byte aligned
+    const size_t acc_off = rt_off + rt_words;                                      // in 32-bit words, 16-byte aligned
     const size_t acc_words = ((size_t)accbins + 1) / 2;
     // The full-vote accumulator, when wanted, is made first, in the same compact array, by all wavefronts: every point
     // votes once per angle (one angle per lane, plain 16-bit counts: there are fewer than 2^14 points), the array goes
@@ -938,7 +964,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     if (tid == 0) fallback[f] = 0;
     c.lacc = reinterpret_cast<int16_t *>(lds32 + acc_off);
     c.lmask = reinterpret_cast<uint64_t *>(lds32 + mask_off);
-    c.rowtab = reinterpret_cast<const uint4 *>(rowtab); c.ymin = ymin; c.nrows = nrows;
+    c.rowtab = reinterpret_cast<const uint2 *>(rowtab); c.wshift = wshift; c.ymin = ymin; c.nrows = nrows;
     c.ltab = s_tab;
     // lane l votes for angle l; lanes past the last angle add zero to a harmless bin instead of branching
     VoteLane vl;
@@ -1023,7 +1049,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
                 const uint32_t pv = i ? lnz[i - 1] : 0u;
                 first[k] = i == 0 || (int)(pv >> 16) != y || ((int)(pv & 0xFFFF) >> 6) != wi;
                 if (first[k]) {
-                    (void)row_word(c.rowtab[y - ymin], wi, widx[k]);
+                    (void)row_word(c.rowtab[row_slot(c, (uint32_t)(y - ymin), wi)], wi, widx[k]);
                     src[k] = c.mask + (size_t)y * c.TX + wi;
                 }
             }
@@ -1218,7 +1244,10 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         g_stamps[5] = n_alive; g_stamps[6] = n_line; g_stamps[7] = n;
         g_more[0] = n_groups; g_more[1] = n_alive; g_more[2] = t_pre; g_more[3] = n_trig_batches; g_more[4] = nseg;
     }
-    if (f < 512 && lane == 0) { g_frame_cycles[2 * f] = STAMP() - tc0; g_frame_cycles[2 * f + 1] = STAMP() - t_kernel0; }
+    if (f < 512 && lane == 0) {
+        g_frame_cycles[2 * f] = STAMP() - tc0; g_frame_cycles[2 * f + 1] = STAMP() - t_kernel0;
+        g_frame_real[f] = __builtin_amdgcn_s_memrealtime() - t_real0;
+    }
 #endif
 }
 
@@ -1273,13 +1302,13 @@ void launch_vote(Geo g, int nframes, const uint32_t *nz, int nz_cap, const int *
 }
 
 int ppht_lds_half() {
-    // LANECV_PPHT_LDS_KB (diagnostics, 16 .. 72): another size for the shared-CU launches, e.g. 48 for three frames per CU
-    static const int kb = [] {
+    // LANECV_PPHT_LDS_KB (diagnostics, 16 .. 72, halves allowed): another size for the shared-CU launches, e.g. 49.5 for three frames per CU
+    static const int half_kb = [] {      // in units of 512 bytes
         const char *e = getenv("LANECV_PPHT_LDS_KB");
-        const int v = e ? atoi(e) : 0;
-        return (v >= 16 && v <= 72) ? v : 0;
+        const double v = e ? atof(e) : 0.0;
+        return (v >= 16.0 && v <= 72.0) ? (int)(2.0 * v) : 0;
     }();
-    return kb ? kb * 1024 : PPHT_LDS_HALF;
+    return half_kb ? half_kb * 512 : PPHT_LDS_HALF;
 }
 
 // HoughLinesP in two steps, so that the caller can put the flagged vote kernel between them (the general
@@ -1339,6 +1368,9 @@ extern "C" int lc_debug_stamps(long long *out) {
 extern "C" int lc_debug_setup(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup), sizeof(long long) * 16); }
 extern "C" int lc_debug_frame_cycles(long long *out, int nframes) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_frame_cycles), sizeof(long long) * 2 * (nframes < 512 ? nframes : 512));
+}
+extern "C" int lc_debug_frame_real(long long *out, int nframes) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_frame_real), sizeof(long long) * (nframes < 512 ? nframes : 512));
 }
 #endif
 
