@@ -230,6 +230,19 @@ def test_hough_lines_p_lds_path_edges(cv2, oracle):
     wide = np.zeros((64, 4096), np.uint8); wide[30, 10:4090] = 255; wide[10:50, 2048] = 255
     wide[(np.arange(4000) // 100 + 5) % 64, np.arange(4000) + 40] = 255
     _same_lines(cv2, oracle, wide, 6, th, 80, 40, 10)
+    # an X of two long diagonals with lone points at the corners and mid-edges: every band of rows has another column
+    # range, and the lone points vote in the first and last bins of the angles' accumulator rows
+    xs = np.zeros((600, 800), np.uint8)
+    t = np.arange(40, 560)
+    xs[t, t + 100] = 255
+    xs[t, 700 - t] = 255
+    for y, x in ((0, 0), (0, 799), (599, 0), (599, 799), (300, 0), (300, 799), (0, 400), (599, 400), (17, 790), (580, 3)):
+        xs[y, x] = 255
+    for rho, thr in ((6, 100), (1, 60), (3.5, 80)):
+        assert _same_lines(cv2, oracle, xs, rho, th, thr, 40, 10) >= 2
+    tall = np.zeros((3000, 96), np.uint8)                                        # 2990 rows of points: bands of 64 rows
+    tall[5:2995, 40] = 255; tall[5:2995:7, 90] = 255; tall[1500, 0:96:3] = 255
+    assert _same_lines(cv2, oracle, tall, 6, th, 100, 40, 10) >= 1
     dense = (rng.random((360, 640)) < 0.03).astype(np.uint8) * 255              # ~6900 points: fits
     _same_lines(cv2, oracle, dense, 6, th, 60, 30, 4)
     denser = (rng.random((360, 640)) < 0.09).astype(np.uint8) * 255             # ~20700 points: general kernel
