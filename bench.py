@@ -509,8 +509,10 @@ def main():
             for s in inflight:
                 pipe.wait(s)
             sfps = ssteps * batch / (time.perf_counter() - t1)
-            rows_from = pipe.rows_uploaded((ssteps - 1) % args.slots)      # with an ROI only the rows the kernels read are copied
-            sent_bytes = 3 * W * (H - rows_from)
+            # with an ROI only what the kernels read is copied: of the rows from a little above the ROI down, per row
+            # segment the columns of the units the front kernel classifies
+            rows_from = pipe.rows_uploaded((ssteps - 1) % args.slots)
+            sent_bytes = pipe.bytes_uploaded((ssteps - 1) % args.slots)
             src = torch.from_numpy(pinned[0].reshape(-1))           # the same pinned block, copied by torch alone
             dst = torch.empty(src.numel(), dtype=torch.uint8, device="cuda")
             best = 0.0
@@ -525,11 +527,11 @@ def main():
                                          "unit": "GB/s", "frac": round(sfps * sent_bytes / 1e9 / best, 4),
                                          "bytes_sent_per_frame": sent_bytes, "first_row_sent": rows_from,
                                          "whole_frame_equivalent_GBs": round(sfps * frame_bytes / 1e9, 2),
-                                         "note": "achieved = bytes actually copied (rows %d..%d of every frame: the rows the "
-                                                 "kernels read with the triangle ROI; a frame that needs the rest after all is "
-                                                 "fetched when its slot is waited for) x frames/s; peak = host-to-device rate of "
-                                                 "one pinned %d-frame batch copied alone, measured in this run"
-                                                 % (rows_from, H - 1, batch)}
+                                         "note": "achieved = bytes actually copied (of rows %d..%d of every frame the column windows "
+                                                 "the front kernel's units read with the triangle ROI, a 3-D copy per row segment; a "
+                                                 "frame that needs the rest after all is fetched when its slot is waited for) x "
+                                                 "frames/s; peak = host-to-device rate of one pinned %d-frame batch copied alone, "
+                                                 "measured in this run" % (rows_from, H - 1, batch)}
             del dst
 
         if world == 1 and not args.no_cpu_baseline:

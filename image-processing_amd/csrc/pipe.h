@@ -16,6 +16,7 @@ struct Slot {
     bool from_host = false;
     const uint8_t *host_src = nullptr;  // host submits: where the frames came from (stays valid until the slot has been waited for)
     int rows_from = 0;                // host submits: the first row of every frame that has been uploaded so far
+    bool windowed = false;            // ... and of those rows only the column windows the tightest level reads (lc_pipe::up_windows)
     bool eager_redo = true;           // its launch classified flagged frames again itself (it could: they were there in full)
     bool busy = false;                // submitted and not yet waited for
     bool pending = false;             // submitted, but the bank's kernels for it are not queued yet
@@ -146,6 +147,13 @@ struct lc_pipe {
     // lc_pipe_wait last saw one.  Otherwise a flagged frame is made up for when its slot is waited for (enqueue_repair).
     int redo_hold = 0;
     DevBuf<int> ones;
+    // What the front kernel reads of a frame at the tightest level, as a few windows (rows [r0, r1), bytes [b0, b1) of each):
+    // per row segment the columns of its needed strips and the rows the units warm up and drain on.  Frames submitted from
+    // host memory while the pipeline is at that level are uploaded window by window (a 3-D copy each); whatever else turns out
+    // to be needed follows as whole rows or whole frames.
+    struct UpWindow { int r0, r1, b0, b1; };
+    std::vector<UpWindow> up_windows;
+    long long up_window_bytes = 0;    // per frame
     long long frame_pixels = 0;
     FrontSplit split(int lvl, int mode, const int *only) const {
         if (lvl >= nlevels) return FrontSplit{row_split, 0, only, nullptr, nullptr, 0, 0};

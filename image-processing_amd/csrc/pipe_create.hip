@@ -200,6 +200,24 @@ int setup_skip_levels(lc_pipe *pp, const std::vector<uint64_t> &bits) {
                     if (e != hipSuccess) return fail(LC_EHIP, "unit list upload failed: %s", hipGetErrorString(e));
                     L.n_needed = (int)needed.size(); L.n_unneeded = (int)unneeded.size(); L.n_ring_words = (int)rw.size();
                     L.pixels = npix;
+                    if (pp->nlevels == 0 && !pp->resizes) {
+                        // the windows of a frame this level's units read: per lower segment the columns from its first needed
+                        // strip's first lane to its last one's last (a strip is 256 columns wide, 4 before its first output
+                        // column), the rows from 4 above the segment to 4 below (blur, Sobel and NMS reach that far)
+                        pp->up_windows.clear();
+                        pp->up_window_bytes = 0;
+                        for (int sg = fg.nseg_top; sg < fg.nseg_top + fg.nseg_low; sg++) {
+                            int smin = INT_MAX, smax = -1;
+                            for (uint16_t u : needed)
+                                if ((u & 255) == sg) { smin = std::min(smin, (int)(u >> 8)); smax = std::max(smax, (int)(u >> 8)); }
+                            if (smax < 0) continue;
+                            const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
+                            const int c0 = std::max(0, smin * fg.strip_cols - 4), c1 = std::min(g.W, smax * fg.strip_cols + 252);
+                            lc_pipe::UpWindow uw{std::max(0, y0 - 4), std::min(H, y1 + 4), 3 * c0, 3 * c1};
+                            pp->up_windows.push_back(uw);
+                            pp->up_window_bytes += (long long)(uw.r1 - uw.r0) * (uw.b1 - uw.b0);
+                        }
+                    }
                     pp->nlevels++;
                     return LC_OK;
                 };

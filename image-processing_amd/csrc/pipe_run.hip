@@ -106,6 +106,23 @@ int upload_rows(lc_pipe *pipe, Slot &s, int r0, int r1) {
     return LC_OK;
 }
 
+// copies the tightest level's windows (lc_pipe::up_windows) of each of the slot's n frames: a 3-D copy per window (bytes of a
+// row x rows x frames)
+int upload_windows(lc_pipe *pipe, Slot &s) {
+    const size_t pitch = (size_t)3 * pipe->src_w;
+    for (const lc_pipe::UpWindow &uw : pipe->up_windows) {
+        hipMemcpy3DParms c = {};
+        c.srcPtr = make_hipPitchedPtr(const_cast<uint8_t *>(s.host_src), pitch, pitch, (size_t)pipe->src_h);
+        c.dstPtr = make_hipPitchedPtr(const_cast<uint8_t *>(s.input), pitch, pitch, (size_t)pipe->src_h);
+        c.srcPos = make_hipPos((size_t)uw.b0, (size_t)uw.r0, 0);
+        c.dstPos = c.srcPos;
+        c.extent = make_hipExtent((size_t)(uw.b1 - uw.b0), (size_t)(uw.r1 - uw.r0), (size_t)s.nframes);
+        c.kind = hipMemcpyHostToDevice;
+        HIP_TRY(hipMemcpy3DAsync(&c, pipe->st_up));
+    }
+    return LC_OK;
+}
+
 hipStream_t next_lines_stream(lc_pipe *pp) {
     if (!pp->p.want_segments) return pp->st_post;
     const unsigned turn = pp->lines_turn++ % (unsigned)(1 + pp->st_lines_more.size());
@@ -217,12 +234,17 @@ int launch_bank(lc_pipe *pp, int bi) {
         Slot &s = first[j];
         if (!s.pending || !s.from_host) continue;
         const int need_from = first_row_read(pp, L.level);
-        if (s.rows_from > need_from) {
+        if (s.windowed && L.level != 0) {            // the level moved out since the submit: whole rows after all
+            int rc;
+            if ((rc = upload_rows(pp, s, need_from, pp->src_h))) return rc;
+            s.rows_from = need_from;
+            s.windowed = false;
+        } else if (s.rows_from > need_from) {
             int rc;
             if ((rc = upload_rows(pp, s, need_from, s.rows_from))) return rc;
             s.rows_from = need_from;
         }
-        eager = eager && s.rows_from == 0;
+        eager = eager && s.rows_from == 0 && !s.windowed;
     }
     static const bool always_eager = getenv("LANECV_EAGER_REDO") && getenv("LANECV_EAGER_REDO")[0] == '1';   // diagnostics
     if (pp->redo_hold > 0) pp->redo_hold--;
@@ -381,8 +403,8 @@ int enqueue_repair(lc_pipe *pp, Slot &s) {
     const lc_pipe_params &p = pp->p;
     Slot *first = &pp->slots[(size_t)s.bank * pp->parts];
     hipStream_t ps = pp->st_post;
-    if (s.from_host && s.rows_from > 0) {
-        const size_t bytes = (size_t)s.rows_from * 3 * pp->src_w;
+    if (s.from_host && (s.rows_from > 0 || s.windowed)) {
+        const size_t bytes = s.windowed ? pp->src_frame_bytes : (size_t)s.rows_from * 3 * pp->src_w;
         for (int i = 0; i < s.nframes; i++)
             if ((s.h_rounds[i] >> 30) & 1)
                 HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(s.input) + (size_t)i * pp->src_frame_bytes, s.host_src + (size_t)i * pp->src_frame_bytes,
@@ -436,7 +458,11 @@ int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nf
     // for the rare frame that must be classified in full after all).  LANECV_FULL_UPLOAD=1: whole frames always.
     static const bool full_upload = getenv("LANECV_FULL_UPLOAD") && getenv("LANECV_FULL_UPLOAD")[0] == '1';
     s->rows_from = full_upload ? 0 : first_row_read(pipe, pipe->nlevels > 0 ? pipe->level : 0);
-    if ((rc = upload_rows(pipe, *s, s->rows_from, pipe->src_h))) return rc;
+    s->windowed = !full_upload && pipe->nlevels > 0 && pipe->level == 0 && !pipe->up_windows.empty() && s->rows_from > 0 &&
+                  !getenv("LANECV_NO_UPLOAD_WINDOWS");
+    if (s->windowed) rc = upload_windows(pipe, *s);
+    else rc = upload_rows(pipe, *s, s->rows_from, pipe->src_h);
+    if (rc) return rc;
     return submit(pipe, *s);
 }
 
@@ -450,6 +476,7 @@ int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nfra
     s->nframes = nframes;
     s->input = (const uint8_t *)dev_bgr;
     s->from_host = false;
+    s->windowed = false;
     s->rows_from = 0;
     return submit(pipe, *s);
 }
@@ -665,6 +692,17 @@ int lc_pipe_rows_uploaded(lc_pipe *pipe, int slot, int *first_row) {
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!first_row) return fail(LC_EINVAL, "null output");
     *first_row = s->from_host ? s->rows_from : 0;
+    return LC_OK;
+}
+
+int lc_pipe_bytes_uploaded(lc_pipe *pipe, int slot, long long *bytes_per_frame) {
+    Slot *s;
+    int rc;
+    if ((rc = get_slot(pipe, slot, &s))) return rc;
+    if (!bytes_per_frame) return fail(LC_EINVAL, "null output");
+    if (!s->from_host) *bytes_per_frame = 0;
+    else if (s->windowed) *bytes_per_frame = pipe->up_window_bytes;
+    else *bytes_per_frame = (long long)(pipe->src_h - s->rows_from) * 3 * pipe->src_w;
     return LC_OK;
 }
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "lc_cvt_gray", "lc_cvt_hsv", "lc_in_range3", "lc_or", "lc_and3_mask", "lc_resize_linear", "lc_add_weighted", "lc_gaussian5", "lc_canny", "lc_canny_noalloc", "lc_fill_poly", "lc_rectangle_filled", "lc_line", "lc_polylines", "lc_and",
     "lc_hough_geometry", "lc_hough_accum", "lc_hough_lines_p", "lc_lds_atomic_rate",
     "lc_pipe_create", "lc_pipe_destroy", "lc_pipe_submit_host", "lc_pipe_submit_device", "lc_pipe_wait",
-    "lc_pipe_read", "lc_pipe_read_points", "lc_pipe_stage_ms", "lc_pipe_input_device_ptr", "lc_pipe_upload", "lc_pipe_hyst_rounds", "lc_pipe_shared_queues", "lc_pipe_roi_skip", "lc_pipe_layout", "lc_pipe_set_timing", "lc_pipe_rows_uploaded", "lc_pipe_event_times",
+    "lc_pipe_read", "lc_pipe_read_points", "lc_pipe_stage_ms", "lc_pipe_input_device_ptr", "lc_pipe_upload", "lc_pipe_hyst_rounds", "lc_pipe_shared_queues", "lc_pipe_roi_skip", "lc_pipe_layout", "lc_pipe_set_timing", "lc_pipe_rows_uploaded", "lc_pipe_bytes_uploaded", "lc_pipe_event_times",
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
         L.lc_pipe_shared_queues.argtypes = [vp, C.POINTER(i)]
         L.lc_pipe_set_timing.argtypes = [vp, i]
         L.lc_pipe_rows_uploaded.argtypes = [vp, i, C.POINTER(i)]
+        L.lc_pipe_bytes_uploaded.argtypes = [vp, i, C.POINTER(C.c_longlong)]
         L.lc_pipe_event_times.argtypes = [vp, i, C.POINTER(C.c_float)]
         L.lc_pipe_layout.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
         L.lc_pipe_roi_skip.argtypes = [vp, i, C.POINTER(i), C.POINTER(C.c_longlong), C.POINTER(i)]

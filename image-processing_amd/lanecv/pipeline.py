@@ -300,6 +300,12 @@ class LanePipeline:
         _abi.check(_abi.lib().lc_pipe_rows_uploaded(self._h, slot, C.byref(v)))
         return v.value
 
+    def bytes_uploaded(self, slot):
+        """Bytes per frame of the slot's last batch that `submit` copied to the GPU (0 for device submits)."""
+        v = C.c_longlong()
+        _abi.check(_abi.lib().lc_pipe_bytes_uploaded(self._h, slot, C.byref(v)))
+        return v.value
+
     def layout(self):
         """(slots per HoughLinesP launch, HoughLinesP streams, levels of the ROI scheme)."""
         a, b, c = C.c_int(), C.c_int(), C.c_int()

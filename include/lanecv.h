@@ -282,6 +282,12 @@ int lc_pipe_roi_skip(lc_pipe *pipe, int slot, int *first_row, long long *pixels_
  * copied to the GPU by lc_pipe_submit_host (0: whole frames, also for batches submitted from device memory).  With an
  * ROI the rows above the first one the kernels read are not copied. */
 int lc_pipe_rows_uploaded(lc_pipe *pipe, int slot, int *first_row);
+/* Diagnostics with no counterpart in the reference: bytes per frame of the slot's last batch that lc_pipe_submit_host
+ * (and whatever the launch fetched after it) copied to the GPU.  With an ROI, while the pipeline classifies only the
+ * units near it, of the rows from *first_row down only the columns those units read are copied; 0 for batches
+ * submitted from device memory.  (Frames that had to be classified in full are fetched whole when the slot is waited
+ * for; they are not counted here.) */
+int lc_pipe_bytes_uploaded(lc_pipe *pipe, int slot, long long *bytes_per_frame);
 /* Diagnostics with no counterpart in the reference: how many of the pipeline's streams found no hardware queue of
  * their own when it was created (HIP folds a process's streams onto GPU_MAX_HW_QUEUES queues; the pipeline probes
  * which ones share).  0 = every stage overlaps as designed; otherwise stages that were meant to run side by side

@@ -543,6 +543,65 @@ def test_rows_follow_when_the_level_moves_out_before_the_launch(oracle, monkeypa
     pipe.close()
 
 
+def test_host_frames_are_uploaded_in_windows(oracle, monkeypatch):
+    """Frames submitted from host memory while the pipeline classifies only the units near the ROI are copied window by
+    window: per row segment the columns its units read.  The slot's device buffer is filled with noise first, so a read
+    outside the windows would show; a frame that needs the full pass after all is fetched whole; and while the pipeline
+    is a level out whole rows are sent."""
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h, B = 960, 540, 4
+    rec = Recipe.north_star(w, h)
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+    g = np.full((h, w), 60, np.int32)
+    g[:100, w // 2 + 40:] += 120
+    g[100:, w // 2 + 40:] += 60
+    faint = np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+    road = [synth.synth_road(w, h, seed=61, t=t) for t in range(B)]
+
+    def run(pipe, slot, frames, redone):
+        pipe.upload(slot, noise[:len(frames)])           # what an earlier batch might have left in the slot's buffer
+        pipe.submit(slot, frames)
+        segs = pipe.collect(slot)
+        masked, acc = pipe.read(slot, _abi.BUF_MASKED), pipe.read(slot, _abi.BUF_ACC)
+        assert pipe.roi_skip(slot)[2] == redone
+        for i, f in enumerate(frames):
+            r = _oracle_frame(oracle, f, rec, pipe.roi)
+            assert (masked[i] == r["masked"]).all() and (acc[i] == r["acc"]).all(), (slot, i)
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (slot, i)
+
+    monkeypatch.setenv("LANECV_SKIP_OFF_BATCHES", "0")      # stay at the tightest level whatever is redone
+    pipe = LanePipeline(w, h, rec, max_batch=B, nslots=2, seg_capacity=512)
+    first = pipe.row_skip(0)[0]
+    rows_bytes = 3 * w * (h - (first - 8))
+    run(pipe, 0, np.stack(road), 0)
+    windows_bytes = pipe.bytes_uploaded(0)
+    assert 0 < windows_bytes < rows_bytes and 0 < pipe.rows_uploaded(0) <= first
+    run(pipe, 1, np.stack([road[0], faint, road[1]]), 1)   # the flagged frame is fetched whole when the slot is waited for
+    assert pipe.bytes_uploaded(1) == windows_bytes
+    run(pipe, 0, np.stack([faint] * B), B)
+    run(pipe, 1, np.stack(road[::-1]), 0)
+    monkeypatch.setenv("LANECV_NO_UPLOAD_WINDOWS", "1")
+    run(pipe, 0, np.stack(road), 0)
+    assert pipe.bytes_uploaded(0) == rows_bytes
+    monkeypatch.delenv("LANECV_NO_UPLOAD_WINDOWS")
+    pipe.close()
+
+    monkeypatch.setenv("LANECV_SKIP_OFF_BATCHES", "2")      # a batch with many frames redone: a level out for two batches
+    pipe = LanePipeline(w, h, rec, max_batch=B, nslots=2, seg_capacity=512)
+    run(pipe, 0, np.stack([faint] * B), B)
+    assert pipe.bytes_uploaded(0) == windows_bytes
+    run(pipe, 1, np.stack(road[::-1]), 0)                   # all columns from above the ROI down: whole rows
+    assert pipe.bytes_uploaded(1) == rows_bytes
+    run(pipe, 0, np.stack(road), 0)
+    run(pipe, 1, np.stack(road), 0)                         # (its launch is back at the units near the ROI; its submit was not yet)
+    run(pipe, 0, np.stack(road[::-1]), 0)
+    assert pipe.bytes_uploaded(0) == windows_bytes
+    pipe.close()
+
+
 @pytest.mark.parametrize("layout", [{"LANECV_TAIL_STREAMS": "0"}, {"LANECV_TAIL_STREAMS": "1"}, {"LANECV_TAIL_STREAMS": "2"},
                                     {"LANECV_TAIL_STREAMS": "2", "LANECV_HYST_LEAD": "1"},
                                     {"LANECV_TAIL_STREAMS": "2", "LANECV_HYST_LEAD": "1", "LANECV_EAGER_REDO": "1"}],
