@@ -47,8 +47,8 @@ out = {
         "SQ_ACTIVE_INST_VALU": round(mean(sq, 'SQ_ACTIVE_INST_VALU')), "SQ_WAVE_CYCLES": round(mean(sq, 'SQ_WAVE_CYCLES')),
         "SQ_WAIT_INST_ANY": round(mean(sq, 'SQ_WAIT_INST_ANY')), "SQ_BUSY_CYCLES": round(mean(sq, 'SQ_BUSY_CYCLES')),
         "launch_us_under_pmc": round(mean(sq, '_dur'), 1),
-        "note": "round 1 (whole frames, before the instruction work): SQ_INSTS_VALU 259.7 M, SQ_INSTS_SALU 127.3 M per launch; the "
-                "whole-frame form of this round's kernel (LANECV_NO_ROW_SKIP=1): 225.8 M / 46.0 M; rows 524..1079 only: 138.3 M / 27.2 M"}}}
+        "note": "the first version of the kernel (whole frames, before the instruction work): SQ_INSTS_VALU 259.7 M, SQ_INSTS_SALU 127.3 M per launch; the "
+                "whole-frame form of the present kernel (LANECV_NO_ROW_SKIP=1): 225.8 M / 46.0 M; rows 524..1079 only: 138.3 M / 27.2 M"}}}
 json.dump(out, open('profiles/%s_pmc_edge_stage.json' % tag, 'w'), indent=1)
 shutil.copy(glob.glob(src + '/bench/**/*kernel_stats.csv', recursive=True)[0], 'profiles/%s_kernel_stats.csv' % tag)
 for a, b in (("bench_under_rocprof.json", "bench_under_rocprof.json"), ("bench.json", "bench.json"),

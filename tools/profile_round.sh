@@ -1,5 +1,5 @@
 #!/bin/bash
-# The rocprofv3 passes behind the numbers in DESIGN.md (run on the GPU box from the repo root):
+# The rocprofv3 passes behind the published kernel figures (run on the GPU box from the repo root):
 #   tools/profile_round.sh <out-dir under gpurun_out/>
 # Kernel trace + stats of the default bench, HBM traffic (FETCH_SIZE, WRITE_SIZE: a pass each) and the SQ counters of the
 # edge-stage kernels alone (tools/front_probe.py), and a kernel trace of a batch-512 run (two frames per CU in one launch).

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The configurations of the recipe table in DESIGN.md, one JSON line each (tools/recipe_probe.py).
+# The configurations of the recipe table (throughput by recipe, size, batch and slots), one JSON line each (tools/recipe_probe.py).
 out=${1:-gpurun_out/recipes.jsonl}
 mkdir -p $(dirname $out)
 : > $out
