@@ -162,8 +162,8 @@ struct lc_pipe {
     }
     bool fuse_vote = true;        // HoughLinesP's kernel also produces the full-vote accumulator (in LDS, before its own)
     // HoughLinesP with half a CU's LDS per frame, so that two frames -- of two batches, on two streams -- share a CU:
-    // the kernel is one sequential wavefront per frame and leaves most of a CU idle.  For frame sizes whose working
-    // set usually fits (up to about 2.5 megapixels; 1080p road frames take 55 - 60 KiB).
+    // the kernel is one sequential wavefront per frame and leaves most of a CU idle.  For pipelines of two banks or more
+    // and frame sizes whose working set usually fits (up to about 2.5 megapixels; 1080p road frames take 47 - 49 KiB).
     // A frame that needs more falls to the slow general kernel; lc_pipe_wait sees it (status word 2) and the next
     // `ppht_full_for` batches get a whole CU's LDS per frame again, after which the half size is tried anew.
     bool ppht_two_per_cu = false;

@@ -295,13 +295,14 @@ int setup_streams(lc_pipe *pp) {
         // Pipelines with three banks or more run the short kernels of a launch on that launch's own HoughLinesP stream
         // (see lc_pipe::tail_streams) and hysteresis on the edge stream.  LANECV_TAIL_STREAMS=0: the post stream
         // layout for them too; =1: hysteresis on the tail streams as well (it then waits for room beside the next
-        // front kernel: measured slower).
+        // front kernel: measured slower).  (Set to 1 or 2 it also applies to pipelines of two banks, where the layout
+        // makes no difference: 505 k frames/s either way at 720p x 32 with 16 slots.)
         const char *ts = getenv("LANECV_TAIL_STREAMS");
         // (Not for launches whose front kernel is no longer than the hysteresis kernel behind it -- 960 x 540 frames in
         // batches of 256: 1.12 M frames/s with the post stream, 1.01 M with this; 1280 x 720: 0.78 M against 0.85 M.)
         const long long classified = (pp->nlevels > 0 ? pp->levels[0].pixels : pp->frame_pixels) * (long long)pp->bank_frames;
         const bool long_front = pp->parts > 1 || classified >= 64ll << 20;
-        pp->tail_streams = own_lines && pp->banks.size() >= 3 && (ts ? ts[0] != '0' : long_front);
+        pp->tail_streams = own_lines && pp->banks.size() >= (ts ? 2u : 3u) && (ts ? ts[0] != '0' : long_front);
         pp->hyst_on_edge = pp->tail_streams && !(ts && ts[0] == '1');
         // LANECV_HYST_LEAD=1: hysteresis not as a kernel of its own on the edge stream but as the first workgroups of the
         // next front launch (lc_pipe::hyst_fused).  Off by default: the edge stream then holds front kernels only (0.33 ms
@@ -433,14 +434,17 @@ int lc_pipe_create(lc_ctx *ctx, const lc_pipe_params *params, lc_pipe **out) {
     pp->line_length = (int)lrint(p.min_line_length);
     pp->line_gap = (int)lrint(p.max_line_gap);
     if (const char *fv = getenv("LANECV_VOTE_FUSED")) pp->fuse_vote = fv[0] != '0';
-    pp->ppht_two_per_cu = p.want_segments && (size_t)p.width * p.height <= 2600000;    // (and three banks or more: setup_streams)
+    pp->ppht_two_per_cu = p.want_segments && (size_t)p.width * p.height <= 2600000;    // (and two banks or more, below)
     if (const char *tp = getenv("LANECV_PPHT_TWO_PER_CU")) pp->ppht_two_per_cu = tp[0] != '0';   // diagnostics
 
     std::vector<uint64_t> bits;
     if ((rc = setup_front_tables(pp))) { lc_pipe_destroy(pp); return rc; }
     setup_layout(pp);
     pp->banks.resize((p.nslots + pp->parts - 1) / pp->parts);     // (their number shapes the stream layout; filled in by setup_banks)
-    if (!getenv("LANECV_PPHT_TWO_PER_CU")) pp->ppht_two_per_cu = pp->ppht_two_per_cu && pp->banks.size() >= 3;
+    // (With two banks as with more: launches of 256 frames that take a whole CU each cannot overlap at all -- 720p x 32 with
+    // 16 slots 420 k -> 505 k frames/s, 1080p x 256 with two slots 315 k -> 404 k, 960 x 540 x 256 with two 555 k -> 779 k.
+    // A single bank has nothing to overlap with, and a frame alone on a CU is served by eight wavefronts instead of four.)
+    if (!getenv("LANECV_PPHT_TWO_PER_CU")) pp->ppht_two_per_cu = pp->ppht_two_per_cu && pp->banks.size() >= 2;
     if ((rc = setup_roi(pp, p, bits)) || (rc = setup_skip_levels(pp, bits)) || (rc = setup_streams(pp)) || (rc = setup_banks(pp))) {
         lc_pipe_destroy(pp);
         return rc;
