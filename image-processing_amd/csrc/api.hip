@@ -138,14 +138,35 @@ int canny_thresholds(double t1, double t2, int &low, int &high) {
     return LC_OK;
 }
 
+// Images of the stand-alone calls come from ordinary (pageable) host memory.  A 2-D copy from or to such memory goes row
+// by row (4.9 ms for a 960 x 540 BGR image, 3.7 ms for its gray image back, against 0.06 and 0.03 ms for the same bytes
+// as one linear copy), so an image whose rows lie back to back is copied linearly, and one with padded rows is packed on
+// the host first.
 int up2d(void *dst, const void *src, size_t row_bytes, int h, size_t stride, hipStream_t st) {
-    HIP_TRY(hipMemcpy2DAsync(dst, row_bytes, src, stride, row_bytes, h, hipMemcpyHostToDevice, st));
+    if (stride == row_bytes) {
+        HIP_TRY(hipMemcpyAsync(dst, src, row_bytes * (size_t)h, hipMemcpyHostToDevice, st));
+        return LC_OK;
+    }
+    static thread_local std::vector<uint8_t> packed;
+    packed.resize(row_bytes * (size_t)h);
+    for (int y = 0; y < h; y++) memcpy(packed.data() + (size_t)y * row_bytes, (const uint8_t *)src + (size_t)y * stride, row_bytes);
+    // (on the stream, then waited for: the buffer is reused by the next call, and the stream does not wait for the null stream)
+    HIP_TRY(hipMemcpyAsync(dst, packed.data(), packed.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return LC_OK;
 }
 int down2d(void *dst, size_t stride, const void *src, size_t row_bytes, int h, hipStream_t st) {
     HIP_TRY(hipGetLastError());   // a kernel launch of the call that failed (bad configuration, missing code object)
-    HIP_TRY(hipMemcpy2DAsync(dst, stride, src, row_bytes, row_bytes, h, hipMemcpyDeviceToHost, st));
+    if (stride == row_bytes) {
+        HIP_TRY(hipMemcpyAsync(dst, src, row_bytes * (size_t)h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return LC_OK;
+    }
+    static thread_local std::vector<uint8_t> packed;
+    packed.resize(row_bytes * (size_t)h);
+    HIP_TRY(hipMemcpyAsync(packed.data(), src, packed.size(), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    for (int y = 0; y < h; y++) memcpy((uint8_t *)dst + (size_t)y * stride, packed.data() + (size_t)y * row_bytes, row_bytes);
     return LC_OK;
 }
 

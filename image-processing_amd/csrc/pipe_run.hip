@@ -456,7 +456,16 @@ int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nf
     // Only the rows the kernels will read: with an ROI level active, those from a little above the first row classified
     // (the level is the one the pipeline is at now; launch_bank fetches the rest should the launch need it, lc_pipe_wait
     // for the rare frame that must be classified in full after all).  LANECV_FULL_UPLOAD=1: whole frames always.
-    static const bool full_upload = getenv("LANECV_FULL_UPLOAD") && getenv("LANECV_FULL_UPLOAD")[0] == '1';
+    static const bool full_upload_env = getenv("LANECV_FULL_UPLOAD") && getenv("LANECV_FULL_UPLOAD")[0] == '1';
+    // Frames in ordinary (pageable) host memory go up whole, as one linear copy: 2-D and 3-D copies from such memory run
+    // row by row (milliseconds for a single 960 x 540 frame), which costs far more than the bytes they save.
+    bool pinned = false;
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, host_bgr) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
+    const bool full_upload = full_upload_env || !pinned;
     s->rows_from = full_upload ? 0 : first_row_read(pipe, pipe->nlevels > 0 ? pipe->level : 0);
     s->windowed = !full_upload && pipe->nlevels > 0 && pipe->level == 0 && !pipe->up_windows.empty() && s->rows_from > 0 &&
                   !getenv("LANECV_NO_UPLOAD_WINDOWS");

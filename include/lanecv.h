@@ -239,8 +239,10 @@ int lc_pipe_destroy(lc_pipe *pipe);
 /* Copies nframes BGR frames from host memory (pinned for true overlap) to the
  * slot on its stream and enqueues the whole pipeline behind the copy.  host_bgr must
  * stay valid and unchanged until lc_pipe_wait on the slot returns: the copy is
- * asynchronous, and with an ROI only the rows the kernels read are copied at first
- * (the rest of a frame follows in the rare case that it is needed after all). */
+ * asynchronous, and from pinned memory, with an ROI, only what the kernels read is
+ * copied at first (the rest of a frame follows in the rare case that it is needed
+ * after all).  Frames in ordinary (pageable) memory are copied whole, as one linear
+ * copy: partial copies from such memory run row by row and cost more than they save. */
 int lc_pipe_submit_host(lc_pipe *pipe, int slot, const uint8_t *host_bgr, int nframes);
 /* Same, but the frames already sit in device memory (no copy is made; the
  * buffer must stay valid and unchanged until lc_pipe_wait on the slot returns: the kernels run some time after

@@ -64,8 +64,12 @@ for b, fr in enumerate(batches):
     slot = b % nslots
     if len(inflight) == nslots:
         check(*inflight.pop(0))
-    if b % 2:                      # device-resident and host frames in turn (the host path uploads the rows the kernels read)
+    if b % 2:                      # device-resident frames, frames in pinned host memory (uploaded in part) and in ordinary memory in turn
         pipe.submit_device(slot, pipe.upload(slot, fr), len(fr))
+    elif b % 4 == 0:
+        buf = pipe.pinned_frames(len(fr))
+        buf[:] = fr
+        pipe.submit(slot, buf)
     else:
         pipe.submit(slot, fr)
     inflight.append((b, slot))

@@ -13,6 +13,13 @@ def _oracle_frame(oracle, f, rec, roi, car=None):
                              want_acc=True, want_segments=True)
 
 
+def _pinned(pipe, frames):
+    """The frames in page-locked memory of the pipeline's (only from such memory are frames uploaded in part)."""
+    buf = pipe.pinned_frames(len(frames))
+    buf[:] = frames
+    return buf
+
+
 def _check_batch(oracle, pipe, frames, rec, slot=0, check_inter=True):
     from lanecv import _abi
     pipe.submit(slot, frames)
@@ -385,11 +392,11 @@ def test_rows_above_the_roi_are_skipped_exactly(oracle, monkeypatch):
     want_redone = [0, 2, 0, 3, 0]
     for b, frames in enumerate(batches):
         assert np.count_nonzero(_oracle_frame(oracle, frames[1 if b in (1,) else 0], rec, pipe.roi)["masked"]) > 0
-        pipe.submit(0, frames)
+        pipe.submit(0, _pinned(pipe, frames))
         segs = pipe.collect(0)
         masked, acc = pipe.read(0, _abi.BUF_MASKED), pipe.read(0, _abi.BUF_ACC)
         assert pipe.row_skip(0)[1] == want_redone[b], b
-        # (submitted from host memory: only the rows from a little above the first one classified were copied, and the
+        # (submitted from pinned host memory: only the rows from a little above the first one classified were copied, and the
         # frames that needed the rows above were fetched in full when the slot was waited for)
         assert 0 < pipe.rows_uploaded(0) <= first
         for i, f in enumerate(frames):
@@ -527,6 +534,7 @@ def test_rows_follow_when_the_level_moves_out_before_the_launch(oracle, monkeypa
 
     first = pipe.row_skip(0)[0]
     a, b_ = np.stack(road[:B]), np.stack(road[B:])
+    a, b_ = _pinned(pipe, a), _pinned(pipe, b_)
     pipe.submit(0, a)                              # bank 0, first slot: copied from a little above row `first`, waits for slot 1
     assert 0 < pipe.rows_uploaded(0) <= first
     for rnd in range(2):                           # bank 1: frames that need the second pass, twice -> out to whole frames
@@ -562,7 +570,7 @@ def test_host_frames_are_uploaded_in_windows(oracle, monkeypatch):
 
     def run(pipe, slot, frames, redone):
         pipe.upload(slot, noise[:len(frames)])           # what an earlier batch might have left in the slot's buffer
-        pipe.submit(slot, frames)
+        pipe.submit(slot, _pinned(pipe, frames))
         segs = pipe.collect(slot)
         masked, acc = pipe.read(slot, _abi.BUF_MASKED), pipe.read(slot, _abi.BUF_ACC)
         assert pipe.roi_skip(slot)[2] == redone
@@ -587,6 +595,9 @@ def test_host_frames_are_uploaded_in_windows(oracle, monkeypatch):
     run(pipe, 0, np.stack(road), 0)
     assert pipe.bytes_uploaded(0) == rows_bytes
     monkeypatch.delenv("LANECV_NO_UPLOAD_WINDOWS")
+    pipe.submit(1, np.stack(road))                       # ordinary (pageable) memory: whole frames, one linear copy
+    pipe.wait(1)
+    assert pipe.rows_uploaded(1) == 0 and pipe.bytes_uploaded(1) == 3 * w * h
     pipe.close()
 
     monkeypatch.setenv("LANECV_SKIP_OFF_BATCHES", "2")      # a batch with many frames redone: a level out for two batches
