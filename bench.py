@@ -158,6 +158,50 @@ def _median_rate(fn, frames, repeats):
     return float(np.median(rates)), [round(r, 2) for r in rates]
 
 
+def single_image():
+    """BASELINE configs[0]: ONE 960 x 540 road image through gray -> GaussianBlur -> Canny -> ROI -> HoughLinesP, call by
+    call through the cv2-shaped module (a NumPy array up and down per call), as the reference's image script runs it; the
+    oracle on one host core beside it.  Milliseconds per image, median of 20."""
+    import numpy as np
+    import lanecv as cv2
+    from lanecv import synth
+    from lanecv.pipeline import triangle_roi
+    from oracle import lane_oracle
+    w, h = 960, 540
+    img = synth.synth_road(w, h, seed=3, t=0)
+    verts = triangle_roi(w, h)
+
+    def script():
+        gray = cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)
+        blur = cv2.GaussianBlur(gray, (5, 5), 0)
+        edges = cv2.Canny(blur, 100, 200)
+        mask = np.zeros_like(edges)
+        cv2.fillPoly(mask, verts, 255)
+        masked = cv2.bitwise_and(edges, mask)
+        return cv2.HoughLinesP(masked, rho=6, theta=np.pi / 60, threshold=160, lines=np.array([]), minLineLength=40, maxLineGap=25)
+
+    def med(fn, n):
+        fn()
+        t = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            t.append(time.perf_counter() - t0)
+        return float(np.median(t)) * 1e3
+
+    got = script()
+    roi = np.zeros((h, w), np.uint8)
+    lane_oracle.fill_poly(roi, verts, 255)
+    ref = lane_oracle.lane_frame(img, 6, True, 100, 200, roi, 6, np.pi / 60, 160, 40, 25, want_acc=False)["segments"]
+    same = (got is None and len(ref) == 0) or (got is not None and got.reshape(-1, 4).shape == ref.shape and (got.reshape(-1, 4) == ref).all())
+    return {"workload": "BASELINE configs[0]: one 960x540 image, cvtColor -> GaussianBlur -> Canny -> fillPoly/bitwise_and -> HoughLinesP, "
+                        "six cv2-shaped calls on NumPy arrays",
+            "ms_per_image": round(med(script, 20), 3),
+            "oracle_one_core_ms": round(med(lambda: lane_oracle.lane_frame(img, 6, True, 100, 200, roi, 6, np.pi / 60, 160, 40, 25,
+                                                                             want_acc=False), 5), 3),
+            "segments": 0 if got is None else len(got), "segments_equal_oracle": bool(same)}
+
+
 def cpu_baseline(frames, rec, roi_vertices, roi, threads, budget_s=24.0):
     """The CPU side of the same recipe on the same frames, on this host: the reference's own cv2 call sequence
     (`Simple Lane Detection with OpenCV_2(images).py:69-92` with the 5x5 blur of `F1_vo_Lane_Tracking.py:97` in front of
@@ -535,6 +579,7 @@ def main():
             del dst
 
         if world == 1 and not args.no_cpu_baseline:
+            out["single_image"] = single_image()
             out["cpu_baseline"] = cpu_baseline(frames[:min(len(frames), 256)], rec, rec.roi_vertices, pipe.roi, host_threads)
         print(json.dumps(out), flush=True)
 
