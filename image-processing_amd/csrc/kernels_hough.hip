@@ -797,9 +797,8 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     __shared__ int s_maskwords, s_accbins;
     // column range of the points in every band of 2^bshift rows (at most PPHT_BANDS bands), and from those the extreme
     // bins of every angle: what sizes the angle's row of the compact accumulator
+    // (these four arrays of 64 words live in the dynamic array, where the accumulator will be: they are dead before it is set up)
     constexpr int PPHT_BANDS = 64;
-    __shared__ int b_lo[PPHT_BANDS], b_hi[PPHT_BANDS];
-    __shared__ int a_lo[64], a_hi[64];
     __shared__ int s_part[PPHT_THREADS];
     __shared__ uint32_t a_base[64], a_rfix[64], a_wid[64];
     __shared__ int a_rmin[64];
@@ -856,7 +855,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     const int wshift = g.TX > 32 ? 1 : 0;
     const int nent = nrows << wshift;                            // row-table entries, two words each
     const size_t rt_words = ((size_t)2 * nent + 3) & ~(size_t)3;
-    if ((rt_off + rt_words) * 4 > (size_t)lds_bytes) {           // (the row table alone does not fit)
+    if ((rt_off + rt_words + 4 * PPHT_BANDS) * 4 > (size_t)lds_bytes) {   // (the row table and the set-up's scratch alone do not fit)
         if (tid == 0) { fallback[f] = 3; status[2] = 1; status[4] = 1; }
         return;
     }
@@ -864,6 +863,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         progress = 0;
         jobs.seq = 0; jobs.done = 0;
     }
+    int *b_lo = reinterpret_cast<int *>(lds32 + rt_off + rt_words), *b_hi = b_lo + PPHT_BANDS, *a_lo = b_hi + PPHT_BANDS, *a_hi = a_lo + 64;
     if (tid < PPHT_BANDS) { b_lo[tid] = INT_MAX; b_hi[tid] = -1; }
     if (tid < 64) { a_lo[tid] = INT_MAX; a_hi[tid] = INT_MIN; }
     int bshift = 0;
