@@ -101,12 +101,23 @@ int front_stream_rows_per_unit(Geo g, int max_batch, int rows_classified);   // 
 // only_frames redoes the frames for which it was not, all units; and before the buffers are next used at a level that
 // skips units a launch in mode 2 clears the plane rows of the other units (`unneeded`) that the full pass stored, so
 // that the next batch finds them empty again.
+// Strips need not start at multiples of 248 columns in every row segment: segment sg's strips start at column
+// 248 * strip - 8 * by8[sg], so that the first strip an ROI needs in that segment begins where the ROI's neighbourhood
+// does (one strip fewer in most segments of a triangle).  nstrips: strips per segment with the shifts applied (one more
+// than front_stream_strips wherever a shifted segment needs it to reach the end of the row).  A pipeline fixes the
+// shifts once: the change tracking behind rowflags is per strip and row.
+constexpr int FRONT_SHIFT_SEGS = 64;
+struct FrontShift {
+    int nstrips;
+    uint8_t by8[FRONT_SHIFT_SEGS];
+};
 struct FrontSplit {
     int row_split;              // > 0: rows above it form a region of units of their own (never needed)
     int mode;                   // 0: all units; 1: the needed units only; 2: clear the plane rows of the unneeded units
     const int *only_frames;     // device flags, one per frame, or null: frames whose flag is 0 are left alone
     const uint16_t *needed, *unneeded;    // device lists of units (segment | strip << 8), or null
     int nneeded, nunneeded;
+    const FrontShift *shift;    // or null: no segment is shifted
 };
 // the unit grid of a frame for a unit height and a split row (what launch_front_stream uses; for building unit lists)
 struct FrontGrid { int nseg_top, rows_top, nseg_low, rows_low, nstrips, strip_cols; };
@@ -146,7 +157,7 @@ void launch_blur5(const uint8_t *src, int W, int H, int nframes, uint8_t *dst, h
 // gate (may be null, 3-channel input only): colour gate in front of the gray conversion.  Frames the
 // streaming kernel cannot take go through a gated gray image first: gate_gray (nframes * W * H bytes)
 // is where it is put, and it may be the same buffer as gray_out.
-// rowflags (may be null; streaming kernel only): nframes * front_stream_strips * H bytes, all zero before the first
+// rowflags (may be null; streaming kernel only): nframes * (front_stream_strips + 1) * H bytes, all zero before the first
 // call like the two planes; with it only strip rows that hold or held a candidate pixel are stored.
 // wake: nframes * TX * TY flags, all zero on entry; the tiles that hold a weak pixel are set (launch_hysteresis
 // consumes and clears them).

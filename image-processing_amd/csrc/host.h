@@ -115,7 +115,7 @@ struct Work {
         if ((rc = rowplane.alloc((size_t)B * g.rowplane_words()))) return rc;
         if (own_input && front_stream_supported(g) && !getenv("LANECV_FRONT_TILED")) {
             // the streaming front kernel then stores only the strip rows that hold or held a candidate pixel
-            const size_t nf = (size_t)B * front_stream_strips(g) * H;
+            const size_t nf = (size_t)B * (front_stream_strips(g) + 1) * H;   // (+ 1: shifted strips, FrontShift)
             if ((rc = rowflags.alloc(nf))) return rc;
             HIP_TRY(hipMemset(rowflags.p, 0, nf));
             HIP_TRY(hipMemset(planeS.p, 0, sizeof(uint64_t) * (size_t)B * g.plane_words()));

@@ -167,6 +167,7 @@ struct FrontArgs {
     int lead_blocks;
     HystArgs lead;
     uint32_t *lead_px;
+    uint8_t shift8[FRONT_SHIFT_SEGS];   // segment sg's strips start at column 248 * strip - 8 * shift8[sg] (FrontShift; all zero: the plain grid)
 };
 
 struct Pair { uint32_t e, o; };   // 4 packed 16-bit values of a lane: e = (px0, px2), o = (px1, px3)
@@ -184,7 +185,7 @@ template <int P> using Phase = std::integral_constant<int, P>;
 // has about 3 KiB of LDS left: one front-end workgroup per CU instead of five.
 // INTER: also store the gray (and blurred) images -- parity runs only; the variant without them keeps their
 // per-lane addresses out of the register budget.
-// One unit: strip s, rows [y0, y1) of frame f.  Two properties of a unit are compile-time switches, so that the
+// One unit: strip s (its first output column is 248 s - 8 d8, d8 the segment's shift), rows [y0, y1) of frame f.  Two properties of a unit are compile-time switches, so that the
 // three quarters of the units that have neither carry none of the per-row tests (scalar instructions, which the
 // four SIMDs of a CU share one issue port for):
 //   HB  the strip holds a lane left of column 0 or right of column W - 1 (first and last strip of a frame row)
@@ -194,11 +195,11 @@ template <int P> using Phase = std::integral_constant<int, P>;
 //       interpolation does it: every sample point falls on a source pixel with the whole weight, so pixel (x, y) IS
 //       source pixel (3x + 1, 3y + 1).  The lane reads its four pixels out of 36 source bytes of every third row.
 template <bool BLUR, int GATE, bool INTER, bool HB, bool FE, bool DEC3 = false>   // GATE: 0 none, 1 the colour gate
-__device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, const int s, const int y0, const int y1) {
+__device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, const int s, const int d8, const int y0, const int y1) {
     const int *__restrict__ gtab = a.gate_tab;
     const int lane = threadIdx.x & 63;
     const int W = a.g.W, H = a.g.H, TX = a.g.TX;
-    const int X0 = STRIP * s - 4;                  // column of lane 0's first pixel
+    const int X0 = STRIP * s - 4 - 8 * d8;         // column of lane 0's first pixel
     const int px = X0 + 4 * lane;
     const bool inimg = px >= 0 && px < W;
     const bool lb = px == -4;                      // the lane left of column 0 (strip 0 only)
@@ -217,8 +218,8 @@ __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, cons
     constexpr int DB = BLUR ? 2 : 0;               // rows the blur delays the pipeline by
     constexpr uint32_t M8 = 0x00FF00FFu;
     // this lane's byte of the two bit planes (odd lanes 1..61 store: their nibble and the next lane's)
-    const int bi = STRIP / 8 * s + ((lane - 1) >> 1);
-    const bool stores = (lane & 1) && lane <= 61 && bi < 8 * TX;
+    const int bi = STRIP / 8 * s - d8 + ((lane - 1) >> 1);
+    const bool stores = (lane & 1) && lane <= 61 && bi >= 0 && bi < 8 * TX;
     const bool emits = lane >= 1 && lane <= 62;
 
     // thresholds: no magnitude exceeds 2040, so anything above behaves like 2041
@@ -486,12 +487,12 @@ __device__ __forceinline__ void front_unit(const FrontArgs &a, const int f, cons
 // stored there (flagged in rowflags, group by group as front_unit does it) are zeroed again, so that the planes
 // above row_split read as empty.
 template <bool BLUR>
-__device__ __forceinline__ void clear_unit(const FrontArgs &a, const int f, const int s, const int y0, const int y1) {
+__device__ __forceinline__ void clear_unit(const FrontArgs &a, const int f, const int s, const int d8, const int y0, const int y1) {
     if (!a.rowflags) return;
     constexpr int DB = BLUR ? 2 : 0;
     const int lane = threadIdx.x & 63, H = a.g.H, TX = a.g.TX;
-    const int bi = STRIP / 8 * s + ((lane - 1) >> 1);
-    const bool stores = (lane & 1) && lane <= 61 && bi < 8 * TX;
+    const int bi = STRIP / 8 * s - d8 + ((lane - 1) >> 1);
+    const bool stores = (lane & 1) && lane <= 61 && bi >= 0 && bi < 8 * TX;
     const size_t flag_base = ((size_t)f * a.nstrips + s) * H;
     const int vend = y1 - 1 + DB + 2;
     for (int v = y0 - (DB + 2); v <= vend + 3; v += 3) {
@@ -533,16 +534,18 @@ __device__ __forceinline__ void front_stream_body(const FrontArgs &a) {
     } else {
         y0 = a.row_split + (sg - a.nseg_top) * a.rows_per_unit; y1 = min(y0 + a.rows_per_unit, H);
     }
-    const bool hb = STRIP * s - 4 < 0 || ((a.g.W - (STRIP * s - 4)) >> 2) <= 63;
+    const int d8 = a.shift8[sg & (FRONT_SHIFT_SEGS - 1)];
+    if (STRIP * s - 8 * d8 >= TILE * a.g.TX) return;    // (a shifted segment's spare strip, past the end of the plane row)
+    const bool hb = STRIP * s - 8 * d8 - 4 < 0 || ((a.g.W - (STRIP * s - 8 * d8 - 4)) >> 2) <= 63;
     const bool fe = y0 == 0 || y1 + DB + 1 >= H;        // rows y0 - DB - 2 .. y1 + DB + 1 are loaded
     auto unit = [&](const int f) {
         if (!a.fs.has(f)) return;
         if (hb) {
-            if (fe) front_unit<BLUR, GATE, INTER, true, true, DEC3>(a, f, s, y0, y1);
-            else front_unit<BLUR, GATE, INTER, true, false, DEC3>(a, f, s, y0, y1);
+            if (fe) front_unit<BLUR, GATE, INTER, true, true, DEC3>(a, f, s, d8, y0, y1);
+            else front_unit<BLUR, GATE, INTER, true, false, DEC3>(a, f, s, d8, y0, y1);
         } else {
-            if (fe) front_unit<BLUR, GATE, INTER, false, true, DEC3>(a, f, s, y0, y1);
-            else front_unit<BLUR, GATE, INTER, false, false, DEC3>(a, f, s, y0, y1);
+            if (fe) front_unit<BLUR, GATE, INTER, false, true, DEC3>(a, f, s, d8, y0, y1);
+            else front_unit<BLUR, GATE, INTER, false, false, DEC3>(a, f, s, d8, y0, y1);
         }
     };
     // every frame: the workgroup's one frame.  Flagged frames only: this wavefront's share of the flags in one
@@ -595,12 +598,14 @@ __global__ __launch_bounds__(256) void k_front_clear(FrontArgs a) {
     int y0, y1;
     if (sg < a.nseg_top) { y0 = sg * a.rows_top; y1 = min(y0 + a.rows_top, a.row_split); }
     else { y0 = a.row_split + (sg - a.nseg_top) * a.rows_per_unit; y1 = min(y0 + a.rows_per_unit, a.g.H); }
+    const int d8 = a.shift8[sg & (FRONT_SHIFT_SEGS - 1)];
+    if (STRIP * s - 8 * d8 >= TILE * a.g.TX) return;
     for (int base = j; base < a.nframes; base += REDO_GROUPS * 64) {
         const int fl = base + REDO_GROUPS * (int)(threadIdx.x & 63);
         uint64_t todo = __ballot(fl < a.nframes && a.only_frames[fl] != 0);
         while (todo) {
             const int f = base + REDO_GROUPS * __builtin_ctzll(todo);
-            if (a.fs.has(f)) clear_unit<BLUR>(a, f, s, y0, y1);
+            if (a.fs.has(f)) clear_unit<BLUR>(a, f, s, d8, y0, y1);
             todo &= todo - 1;
         }
     }
@@ -668,6 +673,11 @@ void launch_front_stream(const uint8_t *src, int code, bool blur, Geo g, int nfr
     a.k_lo = (k0 & 255) | ((k1 & 255) << 8) | ((k2 & 255) << 16);
     a.k_hi = (k0 >> 8) | ((k1 >> 8) << 8) | ((k2 >> 8) << 16);
     a.nstrips = front_stream_strips(g);              // every byte of every plane row is covered
+    for (int k = 0; k < FRONT_SHIFT_SEGS; k++) a.shift8[k] = 0;
+    if (split && split->shift) {
+        a.nstrips = split->shift->nstrips;
+        for (int k = 0; k < FRONT_SHIFT_SEGS; k++) a.shift8[k] = split->shift->by8[k];
+    }
     if (rows_per_unit <= 0) rows_per_unit = front_stream_rows_per_unit(g, nframes, 0);
     if (rows_per_unit > g.H) rows_per_unit = g.H;
     a.rows_per_unit = rows_per_unit;

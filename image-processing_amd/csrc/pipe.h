@@ -154,11 +154,15 @@ struct lc_pipe {
     struct UpWindow { int r0, r1, b0, b1; };
     std::vector<UpWindow> up_windows;
     long long up_window_bytes = 0;    // per frame
+    // where each row segment's strips start (FrontShift): chosen from the tightest level's units, the same for all levels
+    lanecv::FrontShift shift{};
+    bool shifted = false;
     long long frame_pixels = 0;
     FrontSplit split(int lvl, int mode, const int *only) const {
-        if (lvl >= nlevels) return FrontSplit{row_split, 0, only, nullptr, nullptr, 0, 0};
+        const lanecv::FrontShift *sh = shifted ? &shift : nullptr;
+        if (lvl >= nlevels) return FrontSplit{row_split, 0, only, nullptr, nullptr, 0, 0, sh};
         const SkipLevel &L = levels[lvl];
-        return FrontSplit{row_split, mode, only, L.needed.p, L.unneeded.p, L.n_needed, L.n_unneeded};
+        return FrontSplit{row_split, mode, only, L.needed.p, L.unneeded.p, L.n_needed, L.n_unneeded, sh};
     }
     bool fuse_vote = true;        // HoughLinesP's kernel also produces the full-vote accumulator (in LDS, before its own)
     // HoughLinesP with half a CU's LDS per frame, so that two frames -- of two batches, on two streams -- share a CU:

@@ -160,16 +160,42 @@ int setup_skip_levels(lc_pipe *pp, const std::vector<uint64_t> &bits) {
                 pp->row_split = first >= 64 ? first : 0;
                 pp->front_rows = unit_rows(H - pp->row_split);
                 const FrontGrid fg = front_stream_grid(g, pp->front_rows, pp->row_split);
+                // Where each lower segment's strips start: at the first column (rounded down to a plane byte) that comes within
+                // the rings of the ROI in the segment's rows, so that the segment takes the fewest strips that cover its share
+                // of the region -- with a fixed grid a triangle's slanted sides cost about one strip more in most segments.
+                pp->shift = lanecv::FrontShift{};
+                pp->shift.nstrips = fg.nstrips;
+                pp->shifted = false;
+                if (fg.nseg_top + fg.nseg_low <= lanecv::FRONT_SHIFT_SEGS && !getenv("LANECV_NO_STRIP_SHIFT")) {
+                    for (int sg = fg.nseg_top; sg < fg.nseg_top + fg.nseg_low; sg++) {
+                        const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
+                        int first_col = -1;
+                        for (int tx = 0; tx < TX && first_col < 0; tx++) {
+                            uint64_t any = 0;
+                            for (int y = y0; y < y1; y++) any |= cur[(size_t)y * TX + tx];
+                            if (any) first_col = tx * 64 + __builtin_ctzll(any);
+                        }
+                        if (first_col < 0) continue;
+                        const int a8 = first_col & ~7;
+                        const int d = (fg.strip_cols - a8 % fg.strip_cols) % fg.strip_cols;      // 248 * k - d == a8 for some k
+                        pp->shift.by8[sg] = (uint8_t)(d / 8);
+                        if (d) pp->shifted = true;
+                        pp->shift.nstrips = std::max(pp->shift.nstrips, (lanecv::TILE * TX + d + fg.strip_cols - 1) / fg.strip_cols);
+                    }
+                }
+                const int nst = pp->shift.nstrips;
                 // uploads one level: the units a region `reach` (bit plane) touches, and the ring code planes around it
                 auto add_level = [&](const std::vector<uint64_t> &reach, const std::vector<uint64_t> &rcode) -> int {
                     std::vector<uint16_t> needed, unneeded;
                     long long npix = 0;
                     for (int sg = 0; sg < fg.nseg_top + fg.nseg_low; sg++)
-                        for (int st = 0; st < fg.nstrips; st++) {
+                        for (int st = 0; st < nst; st++) {
                             bool need = false;
+                            const int xs = st * fg.strip_cols - 8 * (sg < lanecv::FRONT_SHIFT_SEGS ? pp->shift.by8[sg] : 0);
+                            if (xs >= lanecv::TILE * TX) continue;       // (a shifted segment's spare strip: no unit)
                             if (sg >= fg.nseg_top) {
                                 const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
-                                const int x0 = st * fg.strip_cols, x1 = std::min(x0 + fg.strip_cols, g.W);
+                                const int x0 = std::max(xs, 0), x1 = std::min(xs + fg.strip_cols, g.W);
                                 for (int y = y0; y < y1 && !need; y++)
                                     for (int tx = x0 >> 6; tx <= (x1 - 1) >> 6 && tx < TX && !need; tx++) {
                                         uint64_t v = reach[(size_t)y * TX + tx];
@@ -212,7 +238,8 @@ int setup_skip_levels(lc_pipe *pp, const std::vector<uint64_t> &bits) {
                                 if ((u & 255) == sg) { smin = std::min(smin, (int)(u >> 8)); smax = std::max(smax, (int)(u >> 8)); }
                             if (smax < 0) continue;
                             const int y0 = pp->row_split + (sg - fg.nseg_top) * fg.rows_low, y1 = std::min(y0 + fg.rows_low, H);
-                            const int c0 = std::max(0, smin * fg.strip_cols - 4), c1 = std::min(g.W, smax * fg.strip_cols + 252);
+                            const int shift_cols = 8 * (sg < lanecv::FRONT_SHIFT_SEGS ? pp->shift.by8[sg] : 0);
+                            const int c0 = std::max(0, smin * fg.strip_cols - shift_cols - 4), c1 = std::min(g.W, smax * fg.strip_cols - shift_cols + 252);
                             lc_pipe::UpWindow uw{std::max(0, y0 - 4), std::min(H, y1 + 4), 3 * c0, 3 * c1};
                             pp->up_windows.push_back(uw);
                             pp->up_window_bytes += (long long)(uw.r1 - uw.r0) * (uw.b1 - uw.b0);
@@ -221,7 +248,7 @@ int setup_skip_levels(lc_pipe *pp, const std::vector<uint64_t> &bits) {
                     pp->nlevels++;
                     return LC_OK;
                 };
-                if (fg.nseg_top + fg.nseg_low < 256 && fg.nstrips < 256) {
+                if (fg.nseg_top + fg.nseg_low < 256 && nst < 256) {
                     if ((rc = add_level(cur, code))) return rc;
                     if (pp->row_split > 0) {
                         // the band of rows the ROI spans as the region: ring k = row (first ROI row) - k, all columns
@@ -246,6 +273,8 @@ int setup_skip_levels(lc_pipe *pp, const std::vector<uint64_t> &bits) {
                     }
                 } else {
                     pp->row_split = 0;
+                    pp->shift = lanecv::FrontShift{};
+                    pp->shifted = false;
                 }
             }
         }
@@ -326,7 +355,7 @@ int setup_streams(lc_pipe *pp) {
                 want = std::max(1, std::min(std::min((pp->ppht_two_per_cu ? 2 : 1) * pp->cu_count / pp->bank_frames + (pp->tail_streams ? 1 : 0),
                                                      (int)pp->banks.size()), 3));
             const char *ns = getenv("LANECV_LINES_STREAMS");
-            if (ns && ns[0] >= '1' && ns[0] <= '3') want = ns[0] - '0';   // more than three hung lc_pipe_wait (queue sharing)
+            if (ns && ns[0] >= '1' && ns[0] <= '6') want = ns[0] - '0';   // (only streams that find a hardware queue of their own are taken)
             for (int k = 1; k < want; k++) {
                 hipStream_t st = picker.pick(mine, &own);
                 if (st && own) { pp->st_lines_more.push_back(st); mine.push_back(st); }

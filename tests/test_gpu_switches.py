@@ -15,7 +15,7 @@ SETTINGS = [
     {"LANECV_FRONT_WAVES": "2"}, {"LANECV_FRONT_WAVES": "4"},
     {"LANECV_FRONT_ROWS": "40"},
     {"LANECV_FRONT_TILED": "1"},
-    {"LANECV_NO_ROW_SKIP": "1"},
+    {"LANECV_NO_ROW_SKIP": "1"}, {"LANECV_NO_STRIP_SHIFT": "1"},
     {"LANECV_PPHT_WAVES": "8"},
     {"LANECV_PPHT_LDS_KB": "49.5"}, {"LANECV_PPHT_LDS_KB": "16"},
     {"LANECV_PPHT_TWO_PER_CU": "0"},
