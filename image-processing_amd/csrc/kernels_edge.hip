@@ -475,7 +475,7 @@ void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *pla
                        hipStream_t st, int *status, const int *only_frames, const uint32_t *ring_words, int nring_words,
                        const uint64_t *ring_code, int *redo, const FrameSet *fs, int wake_frames) {
     const HystArgs h = hysteresis_args(g, nframes, planeS, planeW, wake, rounds, status, only_frames, ring_words, nring_words, ring_code, redo, fs, wake_frames);
-    hipLaunchKernelGGL(k_hysteresis, dim3(only_frames ? std::min(nframes, 8) : nframes), dim3(HC_THREADS), 0, st, h);
+    hipLaunchKernelGGL(k_hysteresis, dim3(only_frames ? std::min(nframes, 32) : nframes), dim3(HC_THREADS), 0, st, h);
 }
 
 void launch_finalize(Geo g, int nframes, const uint64_t *planeS, const uint64_t *roi_bits, uint8_t *edges_out,

@@ -41,6 +41,7 @@ struct Bank {
     int parts = 1;
     hipEvent_t ev[12] = {};           // of the bank's latest launch (stage times, and the waits between its streams)
     int planes_level = 0;             // loosest level a launch of this bank ran at since its planes were last cleared down
+    bool redone = false;              // ... and some of its frames were classified again in full since then (their redo flags say which)
     int32_t *h_res = nullptr;         // pinned host mirror of the result block: [segcount][rounds][status 8 * parts][segments]
     bool zero_copy = false;           // the kernels write the result block straight into h_res (mapped pinned memory)
 };
@@ -130,7 +131,7 @@ struct lc_pipe {
     // from row_split down, "rings" = the rows between row_split and the ROI's first row (the same proof around the band of
     // rows the ROI spans: for recipes whose weak pixels connect everything near the ROI, as the F1 tracker's low Canny
     // thresholds do, but not the sky above it).  `level` is what the next batch uses; nlevels = classify in full.  A batch
-    // in which more than a sixteenth of the frames needed the full pass after all moves the pipeline one level out for
+    // in which more than a quarter of the frames needed the full pass after all moves the pipeline one level out for
     // the next 256 batches, after which it tries one level in again.  A slot that goes back to a tighter level has the
     // plane rows of the units that level does not need cleared first (for every frame: `ones`).
     struct SkipLevel {

@@ -363,6 +363,16 @@ int setup_streams(lc_pipe *pp) {
             }
         }
     }
+    if (getenv("LANECV_QUEUE_DEBUG")) {      // diagnostics: which of the pipeline's streams run side by side, after the rejected candidates are gone
+        std::vector<hipStream_t> all{pp->st_edge, pp->st_post, pp->st_lines};
+        for (hipStream_t st : pp->st_lines_more) all.push_back(st);
+        StreamPicker check;
+        for (size_t i = 0; i < all.size(); i++) {
+            for (size_t j = 0; j < all.size(); j++)
+                fprintf(stderr, "%c", i == j || all[i] == all[j] ? '.' : (check.side_by_side(all[i], all[j]) ? '1' : '0'));
+            fprintf(stderr, "  (row spins, column runs beside it: edge, post, lines, more lines)\n");
+        }
+    }
     return LC_OK;
 }
 

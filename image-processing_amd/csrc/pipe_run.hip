@@ -175,15 +175,21 @@ int finish_tail(lc_pipe *pp, bool hysteresis_led) {
         launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, hs, w.r_status, nullptr, SL ? SL->ring_words.p : nullptr,
                           SL ? SL->n_ring_words : 0, SL ? SL->ring_code.p : nullptr, w.redo.p, &L.fs, w.B);
     }
-    if (T.skipping && T.eager) {
+    // The second pass runs where the launch's short kernels run -- with tail streams NOT on the edge stream, whose next
+    // front kernel (another bank's) need not wait for it: the full hysteresis of a frame with a long weak chain is a
+    // quarter of a millisecond of rounds on one workgroup.
+    const bool redo_on_tail = pp->tail_streams && hs != ps && !getenv("LANECV_REDO_ON_EDGE");
+    auto second_pass = [&](hipStream_t st) {
         const FrontSplit again = pp->split(pp->nlevels, 0, w.redo.p);
         launch_front(L.src[0], T.src_bytes, 1, p.color_code, p.blur != 0, w.g, n, pp->low, pp->high, w.planeS.p, w.planeW.p, w.wake.p,
-                     nullptr, nullptr, hs, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, T.fused_resize,
+                     nullptr, nullptr, st, pp->has_gate ? &pp->gate : nullptr, pp->gate_tab.p, w.gray.p, w.rowflags.p, T.fused_resize,
                      pp->front_rows, &again, &L.fs, L.src);
-        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, hs, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs, w.B);
-    }
+        launch_hysteresis(w.g, n, w.planeS.p, w.planeW.p, w.wake.p, w.r_rounds, st, nullptr, w.redo.p, nullptr, 0, nullptr, nullptr, &L.fs, w.B);
+    };
+    if (T.skipping && T.eager && !redo_on_tail) second_pass(hs);
     if (hs != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[EV_HYST], hs));
     if (hs != ps) HIP_TRY(hipStreamWaitEvent(ps, bk.ev[EV_HYST], 0));
+    if (T.skipping && T.eager && redo_on_tail) second_pass(ps);
     enqueue_post(pp, bk, L, ps);
     const int ready = (p.want_accumulator && !vote_is_fused(pp)) ? EV_VOTE : EV_POINTS;
     if (ls != ps || pp->timing) HIP_TRY(hipEventRecord(bk.ev[ready], ps));
@@ -225,7 +231,8 @@ int launch_bank(lc_pipe *pp, int bi) {
     }
     L.level = pp->nlevels > 0 ? pp->level : 0;
     // (no clearing of plane rows beside a launch that may still be reading them: stay at the looser level this once)
-    if (older && L.level < bk.planes_level) L.level = std::min(bk.planes_level, pp->nlevels);
+    const int dirty_level = bk.redone ? pp->nlevels : bk.planes_level;
+    if (older && L.level < dirty_level) L.level = std::min(dirty_level, pp->nlevels);
     // Frames submitted from host memory were uploaded from the first row the level expected at the time reads; if the
     // launch's level reads more, the rows above follow now.  Frames that are not there in full cannot be classified
     // again in the stream: lc_pipe_wait does that for the frames flagged, after fetching the rest of them.
@@ -268,17 +275,21 @@ int launch_bank(lc_pipe *pp, int bi) {
     // (what the tiled kernel may read of a one-slot bank's frames)
     const size_t src_bytes = (size_t)n * (pp->resizes && !fused_resize ? 3 * w.npix : pp->src_frame_bytes);
     if (pp->nlevels > 0) {
-        if (L.level < bk.planes_level) {
+        if (L.level < dirty_level) {
             // Back at a tighter level, or after a batch some of whose frames had to be classified in full (see
             // lc_pipe_wait): the plane rows of the units this level does not need go first.  For every frame the bank
             // holds, not just this launch's: an earlier, larger batch left its bits in the frames behind this one's
-            // too, and a later batch at this level would flood from them.
-            const FrontSplit clear_all = pp->split(L.level, 2, pp->ones.p);
+            // too, and a later batch at this level would flood from them.  If all that happened since the last clearing
+            // is frames classified again, only those frames: their redo flags still stand (a frame's flag is rewritten
+            // by the next launch that covers the frame, which this clearing precedes on the edge stream).
+            const bool flagged_only = bk.redone && L.level >= bk.planes_level;
+            const FrontSplit clear_all = pp->split(L.level, 2, flagged_only ? w.redo.p : pp->ones.p);
             launch_front(L.src[0], src_bytes, 1, p.color_code, p.blur != 0, w.g, bk.parts * p.max_batch, pp->low, pp->high,
                          w.planeS.p, w.planeW.p, w.wake.p, nullptr, nullptr, es, nullptr, nullptr, nullptr, w.rowflags.p, fused_resize,
                          pp->front_rows, &clear_all);
         }
         bk.planes_level = L.level;
+        bk.redone = false;
     }
     // The front kernel -- with the hysteresis of the launch before as its first workgroups, if that is still to come
     HystLaunch lead{};
@@ -503,13 +514,13 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         // Frames the ROI scheme could not settle from the units near the ROI were classified again in full.  Their full
         // passes stored plane rows in units the level does not classify: cleared before the bank's next launch.  And a
         // batch with many of them moves the pipeline a level out.
-        pipe->banks[s->bank].planes_level = pipe->nlevels;
+        pipe->banks[s->bank].redone = true;
         pipe->redo_hold = 64;
         int redone = 0;
         for (int i = 0; i < s->nframes; i++) redone += (s->h_rounds[i] >> 30) & 1;
         const char *ob = getenv("LANECV_SKIP_OFF_BATCHES");         // diagnostics / tests; 0 = never move a level out
         const int off_batches = ob ? atoi(ob) : 256;
-        if (16 * redone > s->nframes && off_batches > 0 && pipe->level <= s->level) {
+        if (4 * redone > s->nframes && off_batches > 0 && pipe->level <= s->level) {
             pipe->level = s->level + 1;
             pipe->level_hold = off_batches;
         }

@@ -24,7 +24,7 @@ SETTINGS = [
     {"LANECV_LINES_STREAMS": "1"}, {"LANECV_LINES_PRIORITY": "0"}, {"LANECV_POST_STREAM": "0", "LANECV_TAIL_STREAMS": "0"},
     {"LANECV_QUEUE_PROBE": "0"},
     {"LANECV_FULL_UPLOAD": "1"}, {"LANECV_NO_UPLOAD_WINDOWS": "1"},
-    {"LANECV_EAGER_REDO": "1"},
+    {"LANECV_EAGER_REDO": "1"}, {"LANECV_EAGER_REDO": "1", "LANECV_REDO_ON_EDGE": "1"},
 ]
 
 

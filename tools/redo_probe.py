@@ -58,6 +58,7 @@ for share in shares:
     print(json.dumps({"share_of_frames_needing_the_second_pass": share, "frames_replaced_per_batch": k,
                       "fps": round(STEPS * B / dt, 1), "ms_per_batch": round(dt / STEPS * 1e3, 4),
                       "pixels_classified_per_frame_last_batch": pixels, "whole_frame": W * H,
-                      "frames_classified_in_full_last_batch": redone}))
+                      "frames_classified_in_full_last_batch": redone,
+                      "streams_sharing_a_queue": pipe.shared_queues(), "layout": pipe.layout()}))
     pipe.close()
     del dev
