@@ -24,7 +24,7 @@ int fail(int code, const char *fmt, ...);
             return fail(LC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int RNG_TABLE = 16384;    // covers every point count the LDS fast path of HoughLinesP accepts
+constexpr int RNG_TABLE = 32768;    // covers every point count the LDS fast path of HoughLinesP accepts
 constexpr int MAX_DIM = 8192;       // 16.16 walk arithmetic and the packed (x | y << 16) points need this bound
 
 template <typename T>

@@ -248,7 +248,11 @@ __device__ long long g_frame_real[512];      // whole kernel per frame in ticks 
 #ifndef PPHT_Q
 #define PPHT_Q 4   // points voting speculatively per group in the LDS path
 #endif
-constexpr int LDS_BIAS = 0x4000;   // offset of the 16-bit accumulator bins kept in LDS
+// Offset of the 16-bit accumulator bins kept in LDS.  A bin's count lies in (-n, n) for n points (a line takes the votes
+// of all its pixels back, voted or not, so counts go negative), and up to PPHT_Q - 1 votes ahead of OpenCV's order are
+// in a bin for a moment: with fewer than LDS_BIAS - 8 points a biased bin stays inside (0, 0xFFFF], and the two bins
+// of a 32-bit word never carry into each other.
+constexpr int LDS_BIAS = 0x8000;
 // Dynamic LDS of the fast HoughLinesP kernel.  MAX: a frame alone on a CU (152 of its 160 KiB; the rest covers the
 // kernel's own static tables and the little the short kernels of other batches need beside it).  HALF: two frames
 // per CU -- 1080p road frames need 55 - 60 KiB -- so that the kernels of two batches run side by side.
@@ -494,9 +498,12 @@ struct LineOut {
 // constants stay in registers.)
 // Returns (accepted ? 1 : 0) | jobs posted so far << 1 (segment number nseg is written if it fits).
 // jobseq is the caller's count of vote-removal jobs posted so far; it lives in registers, not LDS.
-template <bool LDS_STATE, int WAVES = 8>
+// LDS_STATE: accumulator, angle table and vote-removal jobs in LDS (the fast kernel); MASK_LDS: the edge bits in LDS too (else in
+// the frame's bit plane in device memory: the fast kernel's form for frames whose mask words do not fit beside the rest).
+template <bool LDS_STATE, int WAVES = 8, bool MASK_LDS = LDS_STATE>
 __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int i, int max_n, int nseg, Jobs *jb, int jobseq,
                                             const VoteLane &vl, LineOut &lo) {
+    static_assert(LDS_STATE || !MASK_LDS, "the mask is never in LDS without the accumulator");
     constexpr int NC = LDS_STATE ? LINE_NC : LINE_NC_GLOBAL;
     bool inflight = false;   // a vote-removal job of this line is with the helpers
     const AngleEntry e = LDS_STATE ? c.ltab[max_n] : c.tab[max_n];
@@ -511,7 +518,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
     // pass 1: how far the line reaches in each direction.  With the mask in LDS a round trip is cheap, so
     // the walk goes chunk by chunk and stops early (most candidate lines are short); from memory it takes
     // NC chunks per round trip.  The ballots of the first NC chunks are kept: pass 2 needs them again.
-    constexpr int NG = LDS_STATE ? 1 : NC;
+    constexpr int NG = MASK_LDS ? 1 : NC;
     int end_t[2] = {0, 0};
     uint64_t nzm[2][NC] = {};
     uint32_t wword0[2][NC] = {};
@@ -557,7 +564,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
             if (going[0] || going[1]) {
                 uint64_t nz[2][NG], inbm[2][NG];
                 uint32_t ww[2][NG];
-                fetch_chunks<LDS_STATE, NG>(c, wk, lane, g0 * 64, going, nz, inbm, ww);
+                fetch_chunks<MASK_LDS, NG>(c, wk, lane, g0 * 64, going, nz, inbm, ww);
 #pragma unroll
                 for (int k = 0; k < 2; k++)
 #pragma unroll
@@ -571,7 +578,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
         for (int sbase = NC * 64; going[0] || going[1]; sbase += NG * 64) {
             uint64_t nz[2][NG], inbm[2][NG];
             uint32_t ww[2][NG];
-            fetch_chunks<LDS_STATE, NG>(c, wk, lane, sbase, going, nz, inbm, ww);
+            fetch_chunks<MASK_LDS, NG>(c, wk, lane, sbase, going, nz, inbm, ww);
 #pragma unroll
             for (int k = 0; k < 2; k++)
 #pragma unroll
@@ -601,7 +608,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
         } else {
             const bool want[2] = {sbase <= end_t[0], sbase <= end_t[1]};
             uint64_t inbm[2][NC];
-            fetch_chunks<LDS_STATE, NC>(c, wk, lane, sbase, want, bm, inbm, ww);
+            fetch_chunks<MASK_LDS, NC>(c, wk, lane, sbase, want, bm, inbm, ww);
         }
         uint64_t any = 0;
 #pragma unroll
@@ -620,7 +627,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
                 if ((m >> lane) & 1) {
                     int j1, i1;
                     wk.at(base + lane, k ? -1 : 1, j1, i1);
-                    if constexpr (LDS_STATE) {
+                    if constexpr (MASK_LDS) {
                         atomicAnd((unsigned long long *)(c.lmask + ww[k][q]), ~(1ull << (j1 & 63)));
                     } else {
                         atomicAnd((unsigned long long *)(c.mask + (size_t)i1 * c.TX + (j1 >> 6)), ~(1ull << (j1 & 63)));
@@ -664,7 +671,7 @@ __device__ __forceinline__ int extract_line(const Ppht &c, int lane, int j, int 
 #ifdef LC_STAMPS
     long long ts3 = STAMP();
 #endif
-    if constexpr (!LDS_STATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the cleared bits are in L2 before the next pick reads them
+    if constexpr (!MASK_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the cleared bits are in L2 before the next pick reads them
 #ifdef LC_STAMPS
     if (blockIdx.x == 0 && lane == 0) {
         g_dbg[0] += ts1 - ts0; g_dbg[1] += ts2 - ts1; g_dbg[2] += ts3 - ts2; g_dbg[3] += STAMP() - ts3;
@@ -781,7 +788,11 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, int nframes, uint32
 //   point goes to the slot the swap frees, so the array read from the back is the order);
 //   wavefront 0 follows it, with the mask words of the next four points in flight, votes in LDS with
 //   one angle per lane and reduces the maximum with DPP.
-template <int PPHT_WAVES>
+//   MASK_LDS = false: the same with the edge bits left in the frame's bit plane in device memory (no row table, no mask
+//   words in LDS): for frames whose points are so scattered that nearly each sits in a mask word of its own -- points and
+//   accumulator still fit, and a round trip to the L2 per 64 points and per 64 steps of a walk costs a fraction of what the
+//   general kernel's accumulator in device memory does.
+template <int PPHT_WAVES, bool MASK_LDS = true>
 __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint32_t *__restrict__ nz_all, int nz_cap,
                                                    const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
                                                    const AngleEntry *__restrict__ tab, int numangle, int numrho,
@@ -829,7 +840,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         return;
     }
     // status[4]: some frame is left to the general kernel -- which the caller may then launch only when this is raised
-    if (n > lds_points || n >= LDS_BIAS) {   // biased 16-bit bins hold counts in (-LDS_BIAS, LDS_BIAS)
+    if (n > lds_points || n >= LDS_BIAS - 8) {   // biased 16-bit bins hold counts in (-LDS_BIAS, LDS_BIAS)
         if (tid == 0) { fallback[f] = 3; status[4] = 1; }
         return;
     }
@@ -853,7 +864,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     const size_t rt_off = ((size_t)n + 3) & ~(size_t)3;          // 16-byte aligned
     uint32_t *rowtab = lds32 + rt_off;
     const int wshift = g.TX > 32 ? 1 : 0;
-    const int nent = nrows << wshift;                            // row-table entries, two words each
+    const int nent = MASK_LDS ? nrows << wshift : 0;             // row-table entries, two words each
     const size_t rt_words = ((size_t)2 * nent + 3) & ~(size_t)3;
     if ((rt_off + rt_words + 4 * PPHT_BANDS) * 4 > (size_t)lds_bytes) {   // (the row table and the set-up's scratch alone do not fit)
         if (tid == 0) { fallback[f] = 3; status[2] = 1; status[4] = 1; }
@@ -881,7 +892,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         const int x = (int)(pt & 0xFFFF), wi = x >> 6, y = (int)(pt >> 16);
         const uint32_t pv = i ? lnz[i - 1] : 0xFFFFFFFFu, nx = i + 1 < n ? lnz[i + 1] : 0xFFFFFFFFu;
         const bool row_first = (int)(pv >> 16) != y;
-        if (row_first || ((int)(pv & 0xFFFF) >> 6) != wi)
+        if (MASK_LDS && (row_first || ((int)(pv & 0xFFFF) >> 6) != wi))
             atomicOr(&rowtab[2 * ((((uint32_t)(y - ymin)) << wshift) + ((uint32_t)(wi >> 5) & (uint32_t)wshift)) + 1], 1u << (wi & 31));
         if (row_first) atomicMin(&b_lo[(y - ymin) >> bshift], x);
         if ((int)(nx >> 16) != y) atomicMax(&b_hi[(y - ymin) >> bshift], x);
@@ -952,7 +963,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     const size_t acc_off = rt_off + rt_words;                                      // in 32-bit words, 16-byte aligned
     const size_t acc_words = ((size_t)accbins + 1) / 2;
     // The full-vote accumulator, when wanted, is made first, in the same compact array, by all wavefronts: every point
-    // votes once per angle (one angle per lane, plain 16-bit counts: there are fewer than 2^14 points), the array goes
+    // votes once per angle (one angle per lane, plain 16-bit counts: there are fewer than 2^15 points), the array goes
     // out in OpenCV's [angle][rho] shape and is then handed to HoughLinesP.  A few per cent of the frame's time (the
     // sequential loop below dominates), against a second array of the same size that would keep a CU's LDS from
     // holding two frames.
@@ -1033,7 +1044,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     // the kept mask words: the first point of every 64-pixel word fetches the word.  Four points per thread at a time,
     // address arithmetic first, then the loads together, then the stores: one round trip to memory per four words,
     // not one per word (a loop over the rows, a row per wavefront, spent a quarter of the set-up waiting for them).
-    for (int i0 = tid; i0 < n; i0 += 4 * PPHT_THREADS) {
+    for (int i0 = tid; MASK_LDS && i0 < n; i0 += 4 * PPHT_THREADS) {
         uint32_t widx[4];
         const uint64_t *src[4];
         bool first[4];
@@ -1147,7 +1158,8 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         if (lane < m) {
             ptv = lnz[n - 1 - (k + lane)];
             uint32_t widx;
-            alive_l = lds_mask_bit(c, (int)(ptv & 0xFFFF), (int)(ptv >> 16), widx);
+            if constexpr (MASK_LDS) alive_l = lds_mask_bit(c, (int)(ptv & 0xFFFF), (int)(ptv >> 16), widx);
+            else alive_l = (ld_l2(c.mask + (size_t)(ptv >> 16) * c.TX + ((ptv & 0xFFFF) >> 6)) >> (ptv & 63)) & 1;
         }
         const int pjv = (int)(ptv & 0xFFFF), piv = (int)(ptv >> 16);
         const float fjv = (float)pjv, fiv = (float)piv;
@@ -1220,7 +1232,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
                 if (!trig_here) { trig_here = true; n_trig_batches++; }
 #endif
                 LineOut lo;
-                const int lr = extract_line<true, PPHT_WAVES>(c, lane, (int)(hpt & 0xFFFF), (int)(hpt >> 16), max_n, nseg, &jobs, jobseq, vl, lo);
+                const int lr = extract_line<true, PPHT_WAVES, MASK_LDS>(c, lane, (int)(hpt & 0xFFFF), (int)(hpt >> 16), max_n, nseg, &jobs, jobseq, vl, lo);
                 jobseq = lr >> 1;
                 if (lr & 1) nseg++;
                 // which points of the batch the line took: signed step of the lane's point along the major axis
@@ -1318,13 +1330,22 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
                       int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged, int waves,
-                      int status_frames, const FrameSet *fs) {
+                      int status_frames, const FrameSet *fs, bool mask_in_lds) {
     // points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not fit lds_bytes (the
     // kernel decides, per frame) is flagged.
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
     if (lds_bytes <= 0 || lds_bytes > PPHT_LDS_MAX) lds_bytes = PPHT_LDS_MAX;
-    const int lds_points = std::min(rng_len, LDS_BIAS - 1);
-    static LdsOptIn optin8, optin4;
+    const int lds_points = std::min(rng_len, LDS_BIAS - 9);
+    static LdsOptIn optin8, optin4, optin8g;
+    if (!mask_in_lds) {       // the form for scattered points: a frame alone on its CU, eight wavefronts, the mask in device memory
+        static const bool off = getenv("LANECV_NO_SCATTER_KERNEL") != nullptr;   // diagnostics: straight to the general kernel
+        if (off) return true;
+        if (optin8g.ensure(reinterpret_cast<const void *>(k_ppht_fast<8, false>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
+        hipLaunchKernelGGL((k_ppht_fast<8, false>), dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+                           numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
+                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
+        return true;
+    }
     static const char *wv_env = getenv("LANECV_PPHT_WAVES");           // diagnostics: 4 or 8 whatever the LDS size
     const bool four = wv_env ? wv_env[0] == '4' : (waves ? waves == 4 : lds_bytes <= PPHT_LDS_HALF);
     if (four) {

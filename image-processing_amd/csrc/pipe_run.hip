@@ -537,6 +537,12 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         const bool vote_fused = vote_is_fused(pipe);
         hipStream_t ps = pipe->st_post;
         const size_t fo = (size_t)s->pos * p.max_batch, accn = (size_t)w.hg.numangle * w.hg.numrho;
+        // first the LDS kernel's form that reads the mask from device memory (frames whose points are too scattered for
+        // their mask words to fit beside points and accumulator), then the general kernel for what is still flagged
+        (void)launch_ppht_fast(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
+                               w.hg.numangle, w.hg.numrho, p.threshold, pipe->line_length, pipe->line_gap, w.r_seg + fo * w.seg_cap * 4, w.seg_cap,
+                               w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, w.rng_out.p, RNG_TABLE,
+                               vote_fused ? w.acc_full.p + fo * accn : nullptr, ps, 0, true, 8, 0, nullptr, false);
         launch_ppht_general(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
                             w.hg.numangle, w.hg.numrho, w.acc_ppht.p + fo * accn, p.threshold, pipe->line_length, pipe->line_gap,
                             w.r_seg + fo * w.seg_cap * 4, w.seg_cap, w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, ps,
