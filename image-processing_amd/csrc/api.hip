@@ -500,12 +500,14 @@ int lc_hough_lines_p(lc_ctx *ctx, const uint8_t *img, int w, int h, size_t strid
     HIP_TRY(hipMemsetAsync(wk.status.p, 0, 8 * sizeof(int), ctx->stream));
     const int line_length = (int)lrint(min_line_length), line_gap = (int)lrint(max_line_gap);
     const bool fast = launch_ppht_fast(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, threshold, line_length,
-                                       line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, RNG_TABLE,
+                                       line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, wk.rng_len,
                                        nullptr, ctx->stream);
-    // (a frame whose points are too scattered for its mask words to fit: the mask from device memory, before the general kernel)
-    if (fast) (void)launch_ppht_fast(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, threshold, line_length,
-                                     line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, RNG_TABLE, nullptr,
-                                     ctx->stream, 0, true, 8, 0, nullptr, false);
+    // (a frame whose points are too scattered for its mask words to fit, or too many: the mask, then the points as well, from
+    // device memory, before the general kernel)
+    for (int state = 1; fast && state <= 2; state++)
+        (void)launch_ppht_fast(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, threshold, line_length,
+                               line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, wk.fallback.p, wk.rng_out.p, wk.rng_len, nullptr,
+                               ctx->stream, 0, true, 8, 0, nullptr, state);
     launch_ppht_general(wk.g, 1, wk.nz.p, wk.nz_cap, wk.npoints.p, wk.rowplane.p, wk.tab.p, na, nr, wk.acc_ppht.p, threshold, line_length,
                         line_gap, wk.seg.p, cap, wk.segcount.p, wk.status.p, fast ? wk.fallback.p : nullptr, ctx->stream);
     HIP_TRY(hipGetLastError());

@@ -236,9 +236,10 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
                       int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes = 0, bool only_flagged = false, int waves = 0,
-                      int status_frames = 0, const FrameSet *fs = nullptr, bool mask_in_lds = true);
-// mask_in_lds = false: the form of the kernel that leaves the edge bits in the bit plane in device memory (with only_flagged,
-// between a launch of the ordinary form and the general kernel: it takes the frames whose mask words did not fit)
+                      int status_frames = 0, const FrameSet *fs = nullptr, int device_state = 0);
+// device_state 1: the form of the kernel that leaves the edge bits in the bit plane in device memory, 2: the point list as
+// well, permuted in place (with only_flagged, in this order between a launch of the ordinary form and the general kernel:
+// they take the frames whose mask words, or points, did not fit the LDS beside the accumulator)
 // status_frames: 0 = one block of status words for the launch; n = frames [k n, (k + 1) n) raise status + 8 k (a launch
 // over the batches of several pipeline slots, each with status words of its own)
 // waves: 8 or 4 wavefronts per frame (0: 4 with ppht_lds_half(), else 8).  Four is for launches that fill every CU twice

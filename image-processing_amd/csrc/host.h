@@ -24,7 +24,7 @@ int fail(int code, const char *fmt, ...);
             return fail(LC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int RNG_TABLE = 32768;    // covers every point count the LDS fast path of HoughLinesP accepts
+constexpr int RNG_TABLE = 32768, RNG_TABLE_MAX = 1 << 20;    // covers every point count the LDS fast path of HoughLinesP accepts
 constexpr int MAX_DIM = 8192;       // 16.16 walk arithmetic and the packed (x | y << 16) points need this bound
 
 template <typename T>
@@ -79,7 +79,8 @@ struct Work {
     int nz_cap = 0;
     DevBuf<int32_t> acc_full, acc_ppht, seg;
     DevBuf<AngleEntry> tab;
-    DevBuf<uint32_t> rng_out;     // first RNG_TABLE outputs of cv::RNG(2^64 - 1), HoughLinesP's fixed seed
+    DevBuf<uint32_t> rng_out;     // first rng_len outputs of cv::RNG(2^64 - 1), HoughLinesP's fixed seed
+    int rng_len = 0;
     HoughGeo hg;
     double rho = 0, theta = 0;
     int seg_cap = 0;
@@ -159,16 +160,19 @@ struct Work {
             acc_full.release();
             acc_ppht.release();
         }
-        if (ppht && !rng_out.p) {
-            std::vector<uint32_t> r(RNG_TABLE);
+        // one output per point a frame can have, up to RNG_TABLE_MAX (frames with more go to the general kernel, which steps the generator itself)
+        const int rng_want = std::max(RNG_TABLE, std::min(nz_cap, RNG_TABLE_MAX));
+        if (ppht && rng_len < rng_want) {
+            std::vector<uint32_t> r(rng_want);
             unsigned long long state = 0xFFFFFFFFFFFFFFFFull;
-            for (int k = 0; k < RNG_TABLE; k++) {
+            for (int k = 0; k < rng_want; k++) {
                 state = (unsigned long long)(uint32_t)state * 4164903690ull + (state >> 32);
                 r[k] = (uint32_t)state;
             }
-            if ((rc = rng_out.alloc(RNG_TABLE))) return rc;
-            HIP_TRY(hipMemcpyAsync(rng_out.p, r.data(), sizeof(uint32_t) * RNG_TABLE, hipMemcpyHostToDevice, st));
+            if ((rc = rng_out.alloc(rng_want))) return rc;
+            HIP_TRY(hipMemcpyAsync(rng_out.p, r.data(), sizeof(uint32_t) * rng_want, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
+            rng_len = rng_want;
         }
         size_t accn = (size_t)B * hg.numangle * hg.numrho;
         if (full && acc_full.n < accn && (rc = acc_full.alloc(accn))) return rc;

@@ -792,7 +792,10 @@ __global__ __launch_bounds__(256) void k_ppht_general(Geo g, int nframes, uint32
 //   words in LDS): for frames whose points are so scattered that nearly each sits in a mask word of its own -- points and
 //   accumulator still fit, and a round trip to the L2 per 64 points and per 64 steps of a walk costs a fraction of what the
 //   general kernel's accumulator in device memory does.
-template <int PPHT_WAVES, bool MASK_LDS = true>
+//   POINTS_LDS = false (with MASK_LDS = false): the point list stays in device memory too and is permuted in place there,
+//   a round trip to the L2 per 64 picks and per 64 points; only the accumulator is in LDS.  For frames with more points
+//   than fit beside it.
+template <int PPHT_WAVES, bool MASK_LDS = true, bool POINTS_LDS = true>
 __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint32_t *__restrict__ nz_all, int nz_cap,
                                                    const int *__restrict__ npoints, uint64_t *__restrict__ rowplane,
                                                    const AngleEntry *__restrict__ tab, int numangle, int numrho,
@@ -824,7 +827,9 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     const long long t_kernel0 = STAMP();
     const long long t_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    static_assert(POINTS_LDS || !MASK_LDS, "the mask words in LDS are found through the points in LDS");
     const uint32_t *nz = nz_all + (size_t)f * nz_cap;
+    uint32_t *gnz = const_cast<uint32_t *>(nz);       // (POINTS_LDS = false) the list, permuted in place: L2-served accesses only
     if (only_flagged && !(fallback[f] & 1)) return;   // second launch (more LDS per frame): the frames the first one left
     const int n = npoints[f];
     if (n > nz_cap) {
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         return;
     }
     // status[4]: some frame is left to the general kernel -- which the caller may then launch only when this is raised
-    if (n > lds_points || n >= LDS_BIAS - 8) {   // biased 16-bit bins hold counts in (-LDS_BIAS, LDS_BIAS)
+    if (n > lds_points) {                    // (the host's limit: what the biased 16-bit bins and the table of random numbers hold)
         if (tid == 0) { fallback[f] = 3; status[4] = 1; }
         return;
     }
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     uint32_t *lnz = lds32;
     const int ymin = (int)(nz[0] >> 16), ymax = (int)(nz[n - 1] >> 16);
     const int nrows = ymax - ymin + 1;
-    const size_t rt_off = ((size_t)n + 3) & ~(size_t)3;          // 16-byte aligned
+    const size_t rt_off = POINTS_LDS ? ((size_t)n + 3) & ~(size_t)3 : 0;          // 16-byte aligned
     uint32_t *rowtab = lds32 + rt_off;
     const int wshift = g.TX > 32 ? 1 : 0;
     const int nent = MASK_LDS ? nrows << wshift : 0;             // row-table entries, two words each
@@ -882,15 +887,16 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     for (int r = tid; r < 2 * nent; r += PPHT_THREADS) rowtab[r] = 0;
     if (tid < numangle) s_tab[tid] = tab[tid];
     __syncthreads();
-    for (int i = tid; i < n; i += PPHT_THREADS) lnz[i] = nz[i];
+    for (int i = tid; POINTS_LDS && i < n; i += PPHT_THREADS) lnz[i] = nz[i];
     __syncthreads();
     SETUP_MARK(0);
+    const uint32_t *snz = POINTS_LDS ? lnz : nz;      // the sorted list, as the set-up reads it
     for (int i = tid; i < n; i += PPHT_THREADS) {
         // the first point of every 64-pixel word marks the word in its row's map; the first and the last point of a
         // row (its leftmost and rightmost) widen the column range of the row's band
-        const uint32_t pt = lnz[i];
+        const uint32_t pt = snz[i];
         const int x = (int)(pt & 0xFFFF), wi = x >> 6, y = (int)(pt >> 16);
-        const uint32_t pv = i ? lnz[i - 1] : 0xFFFFFFFFu, nx = i + 1 < n ? lnz[i + 1] : 0xFFFFFFFFu;
+        const uint32_t pv = i ? snz[i - 1] : 0xFFFFFFFFu, nx = i + 1 < n ? snz[i + 1] : 0xFFFFFFFFu;
         const bool row_first = (int)(pv >> 16) != y;
         if (MASK_LDS && (row_first || ((int)(pv & 0xFFFF) >> 6) != wi))
             atomicOr(&rowtab[2 * ((((uint32_t)(y - ymin)) << wshift) + ((uint32_t)(wi >> 5) & (uint32_t)wshift)) + 1], 1u << (wi & 31));
@@ -994,7 +1000,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         __syncthreads();
         for (int p0 = wave * 64; p0 < n; p0 += PPHT_WAVES * 64) {
             const int m = min(64, n - p0);
-            const uint32_t ptv = lane < m ? lnz[p0 + lane] : 0u;
+            const uint32_t ptv = lane < m ? snz[p0 + lane] : 0u;
             const float fjv = (float)(ptv & 0xFFFF), fiv = (float)(ptv >> 16);
             // four points at a time as straight-line code (coordinates out of the lanes first, then the four bins, then
             // the four adds): one point per iteration left the wavefront waiting on every step of its own chain
@@ -1100,8 +1106,8 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
             if (on) {
                 idx = rcur % (uint32_t)(n - k);
                 cpos = (uint32_t)(n - k - 1);
-                acur = lnz[idx];
-                bcur = lnz[cpos];
+                acur = POINTS_LDS ? lnz[idx] : ld_l2(gnz + idx);
+                bcur = POINTS_LDS ? lnz[cpos] : ld_l2(gnz + cpos);
             }
             uint64_t overwritten = 0;   // picks whose slot a later pick of the batch writes again
             for (int t = 0; t < m; t++) {
@@ -1116,11 +1122,20 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
                 if (same_a) overwritten |= 1ull << t;
             }
             // lane t: acur = the point pick t removes, bcur = the last element that takes its slot
-            if (on && !((overwritten >> lane) & 1)) lnz[idx] = bcur;
-            if (on) lnz[cpos] = acur;             // after the slot writes: a later pick's own slot wins
-            if (lane == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                *(volatile int *)&progress = k0 + m;
+            if constexpr (POINTS_LDS) {
+                if (on && !((overwritten >> lane) & 1)) lnz[idx] = bcur;
+                if (on) lnz[cpos] = acur;             // after the slot writes: a later pick's own slot wins
+                if (lane == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    *(volatile int *)&progress = k0 + m;
+                }
+            } else {
+                // in device memory no two stores of a batch may meet in a word (nothing orders them there): a picked slot
+                // among the batch's last m slots is some later pick's own slot, whose store wins -- it is left out here
+                if (on && !((overwritten >> lane) & 1) && idx < (uint32_t)(n - k0 - m)) st_l2(gnz + idx, bcur);
+                if (on) st_l2(gnz + cpos, acur);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the stores are in the L2 before the consumer (and the next batch's loads) look
+                if (lane == 0) *(volatile int *)&progress = k0 + m;
             }
         }
 #ifdef LC_STAMPS
@@ -1156,7 +1171,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
         uint32_t ptv = 0;
         bool alive_l = false;
         if (lane < m) {
-            ptv = lnz[n - 1 - (k + lane)];
+            ptv = POINTS_LDS ? lnz[n - 1 - (k + lane)] : ld_l2(gnz + (n - 1 - (k + lane)));
             uint32_t widx;
             if constexpr (MASK_LDS) alive_l = lds_mask_bit(c, (int)(ptv & 0xFFFF), (int)(ptv >> 16), widx);
             else alive_l = (ld_l2(c.mask + (size_t)(ptv >> 16) * c.TX + ((ptv & 0xFFFF) >> 6)) >> (ptv & 63)) & 1;
@@ -1330,18 +1345,33 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
                       int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged, int waves,
-                      int status_frames, const FrameSet *fs, bool mask_in_lds) {
+                      int status_frames, const FrameSet *fs, int device_state) {
     // points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not fit lds_bytes (the
     // kernel decides, per frame) is flagged.
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
     if (lds_bytes <= 0 || lds_bytes > PPHT_LDS_MAX) lds_bytes = PPHT_LDS_MAX;
-    const int lds_points = std::min(rng_len, LDS_BIAS - 9);
-    static LdsOptIn optin8, optin4, optin8g;
-    if (!mask_in_lds) {       // the form for scattered points: a frame alone on its CU, eight wavefronts, the mask in device memory
+    // A bin's count stays inside (-n, n) for n points: fewer than LDS_BIAS - 8 keep the biased 16-bit bins in range.
+    int lds_points = std::min(rng_len, LDS_BIAS - 9);
+    static LdsOptIn optin8, optin4, optin8g, optin8p;
+    if (device_state) {       // the forms for many or scattered points: a frame alone on its CU, eight wavefronts
         static const bool off = getenv("LANECV_NO_SCATTER_KERNEL") != nullptr;   // diagnostics: straight to the general kernel
         if (off) return true;
-        if (optin8g.ensure(reinterpret_cast<const void *>(k_ppht_fast<8, false>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
-        hipLaunchKernelGGL((k_ppht_fast<8, false>), dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+        if (device_state == 1) {
+            if (optin8g.ensure(reinterpret_cast<const void *>(k_ppht_fast<8, false>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
+            hipLaunchKernelGGL((k_ppht_fast<8, false>), dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+                               numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
+                               lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
+            return true;
+        }
+        // Points in device memory: their number is no longer bounded by the LDS.  A bin's count is also bounded by the
+        // pixels whose votes can land in it -- a stripe one bin (rho pixels) wide across the frame: per row (or per
+        // column, whichever the stripe crosses more steeply) at most floor(sqrt(2) * rho) + 1 pixels -- and where that
+        // bound keeps the 16-bit bins in range, the table of random numbers alone limits the points.
+        const double rho_est = (2.0 * (g.W + g.H) + 1.0) / std::max(1.0, numrho - 0.5);      // numrho = round((2 (W + H) + 1) / rho)
+        const long long stripe = (long long)std::max(g.W, g.H) * ((long long)std::floor(1.4143 * rho_est) + 3);
+        if (stripe < LDS_BIAS - 8) lds_points = rng_len;
+        if (optin8p.ensure(reinterpret_cast<const void *>(k_ppht_fast<8, false, false>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
+        hipLaunchKernelGGL((k_ppht_fast<8, false, false>), dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
                            lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
         return true;

@@ -51,7 +51,7 @@ void enqueue_lines(lc_pipe *pp, Bank &bk, Slot *first, const Launch &L, hipStrea
     if (p.want_segments) {
         fast = launch_ppht_fast(w.g, L.nframes, w.nz.p, w.nz_cap, w.npoints.p, w.rowplane.p, w.tab.p, w.hg.numangle, w.hg.numrho,
                                 p.threshold, pp->line_length, pp->line_gap, w.r_seg, w.seg_cap, w.r_segcount, w.r_status, w.fallback.p,
-                                w.rng_out.p, RNG_TABLE, vote_fused ? w.acc_full.p : nullptr, ls,
+                                w.rng_out.p, w.rng_len, vote_fused ? w.acc_full.p : nullptr, ls,
                                 (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false,
                                 2 * L.nframes > pp->cu_count ? 0 : 8, p.max_batch, &L.fs);
         if (pp->ppht_full_for > 0) pp->ppht_full_for--;
@@ -537,12 +537,14 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         const bool vote_fused = vote_is_fused(pipe);
         hipStream_t ps = pipe->st_post;
         const size_t fo = (size_t)s->pos * p.max_batch, accn = (size_t)w.hg.numangle * w.hg.numrho;
-        // first the LDS kernel's form that reads the mask from device memory (frames whose points are too scattered for
-        // their mask words to fit beside points and accumulator), then the general kernel for what is still flagged
-        (void)launch_ppht_fast(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
-                               w.hg.numangle, w.hg.numrho, p.threshold, pipe->line_length, pipe->line_gap, w.r_seg + fo * w.seg_cap * 4, w.seg_cap,
-                               w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, w.rng_out.p, RNG_TABLE,
-                               vote_fused ? w.acc_full.p + fo * accn : nullptr, ps, 0, true, 8, 0, nullptr, false);
+        // first the LDS kernel's forms that read the mask, then the points as well, from device memory (frames whose points
+        // are too scattered for their mask words to fit beside points and accumulator, or too many), then the general
+        // kernel for what is still flagged
+        for (int state = 1; state <= 2; state++)
+            (void)launch_ppht_fast(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
+                                   w.hg.numangle, w.hg.numrho, p.threshold, pipe->line_length, pipe->line_gap, w.r_seg + fo * w.seg_cap * 4, w.seg_cap,
+                                   w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, w.rng_out.p, w.rng_len,
+                                   vote_fused ? w.acc_full.p + fo * accn : nullptr, ps, 0, true, 8, 0, nullptr, state);
         launch_ppht_general(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
                             w.hg.numangle, w.hg.numrho, w.acc_ppht.p + fo * accn, p.threshold, pipe->line_length, pipe->line_gap,
                             w.r_seg + fo * w.seg_cap * 4, w.seg_cap, w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, ps,

@@ -247,17 +247,25 @@ def test_hough_lines_p_lds_path_edges(cv2, oracle):
     _same_lines(cv2, oracle, dense, 6, th, 60, 30, 4)
     denser = (rng.random((360, 640)) < 0.09).astype(np.uint8) * 255             # ~20700 points: still fits
     _same_lines(cv2, oracle, denser, 6, th, 150, 30, 4)
-    densest = (rng.random((360, 640)) < 0.16).astype(np.uint8) * 255            # ~36900 points: general kernel
+    densest = (rng.random((360, 640)) < 0.16).astype(np.uint8) * 255            # ~36900 points: the point list stays in device memory
     _same_lines(cv2, oracle, densest, 6, th, 260, 30, 4)
     # points scattered over a 1080p frame, nearly each in a mask word of its own, and lines through them: points and
-    # accumulator fit the LDS, the mask words do not (the kernel's form that leaves the mask in device memory)
-    for dens, thr in ((0.003, 120), (0.005, 160)):
+    # accumulator fit the LDS, the mask words do not (the kernel's form that leaves the mask in device memory); at the
+    # last density (~42 000 points) the points do not fit either (the form that leaves them in device memory too)
+    for dens, thr in ((0.003, 120), (0.005, 160), (0.02, 220)):
         scat = (rng.random((1080, 1920)) < dens).astype(np.uint8) * 255
         xx = np.arange(100, 1800, 2)
         scat[(1000 - 0.45 * xx).astype(int), xx] = 255
         scat[(200 + 0.3 * xx).astype(int), xx] = 255
         scat[300:900, 960] = 255
         assert _same_lines(cv2, oracle, scat, 6, th, thr, 40, 25) >= 3
+    # a 4K map: a bin-wide stripe across it holds more pixels than a 16-bit bin counts, so there the limit stays 32 759
+    # points -- below it the kernel's forms, above it the global-memory kernel
+    for dens in (0.003, 0.0045):
+        big4k = (rng.random((2160, 3840)) < dens).astype(np.uint8) * 255
+        xx = np.arange(200, 3600, 2)
+        big4k[(2000 - 0.45 * xx).astype(int), xx] = 255
+        assert _same_lines(cv2, oracle, big4k, 6, th, 300, 40, 25) >= 1
 
 
 def test_errors(cv2):

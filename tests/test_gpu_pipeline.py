@@ -215,8 +215,10 @@ def test_one_slot_many_batches(oracle, keep):
 def test_dense_frames_take_the_flagged_paths(oracle, w, h, lo, hi):
     """Frames whose points, accumulator and mask words do not fit the LDS share a launch leaves a frame are flagged by
     the HoughLinesP kernel and done again when the slot is collected: with the mask left in device memory if points and
-    accumulator alone fit a whole CU's LDS (the smaller case), else (more than 32 759 points: the larger case) by the
-    global-memory kernel, which also makes their full-vote accumulator.  Flagged and ordinary frames share a batch.
+    accumulator alone fit a whole CU's LDS (the smaller case), else (the larger case) with the point list left there as
+    well; either way the kernel also makes their full-vote accumulator.  Flagged and ordinary frames share a batch.
+    (The global-memory kernel behind these two takes recipes of more than 64 angles -- tests/test_gpu_ops.py -- and, with
+    LANECV_NO_SCATTER_KERNEL=1, the flagged frames of tests/test_gpu_switches.py.)
     The frame is noise above a flat lower part, sized so that the count lands in the wanted range and under the
     pipeline's point capacity (an eighth of the pixels)."""
     from lanecv import synth, _abi
