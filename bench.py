@@ -396,15 +396,19 @@ def main():
                    "edge": _abi.STAGE_EDGE, "points": _abi.STAGE_POINTS, "vote": _abi.STAGE_VOTE,
                    "lines": _abi.STAGE_LINES, "total": _abi.STAGE_TOTAL}
 
+    trace = [] if os.environ.get("LANECV_BENCH_TRACE") == "1" else None    # diagnostics: when each wait of the timed run returned
+
     def run(job_list, collect_stages=None, keep=None):
-        """Pushes the jobs through the slots in order; keep (a list) receives each batch's (rows, counts) unpadded."""
+        """Pushes the jobs through the slots in order; keep (a shard.RowSink) receives each batch's segments unpadded."""
         inflight = []
 
         def finish(s):
             seg, cnt = pipe.wait(s)
+            if trace is not None and keep is not None:
+                trace.append(time.perf_counter())
             results[s] = (seg, cnt)
             if keep is not None:
-                keep.append((shard.compact(seg, cnt), cnt))
+                keep.append(seg, cnt)
             if collect_stages is not None:
                 collect_stages.append({n: pipe.stage_ms(s, i) for n, i in stage_names.items()})
 
@@ -425,18 +429,24 @@ def main():
     if jobs:
         run([jobs[k % len(jobs)] for k in range(args.warmup)])
     note("warm-up done")
-    stages, kept = [], []
+    stages, kept = [], shard.RowSink(sum(n for _, n in jobs), SEG_CAP)      # the rank's result buffer: allocated before the clock starts
     barrier()
     t0 = time.perf_counter()
     run(jobs, stages, kept)
     note("timed batches done")
     # the final result gather, the path's only exchange between ranks: every frame's segments of every clip, unpadded
-    rows = np.concatenate([r for r, _ in kept]) if kept else np.zeros((0, 4), np.int32)
-    counts = np.concatenate([c for _, c in kept]) if kept else np.zeros(0, np.int32)
-    gathered = shard.gather_compact(rows, counts, dst=0, device=coll_device if use_dist else None)
+    gathered = shard.gather_compact(kept.rows(), kept.counts(), dst=0, device=coll_device if use_dist else None)
     note("gathered")
+    if trace is not None:
+        t_g = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    if trace is not None:
+        print("[trace] waits returned at (ms): %s; gathered at %.3f; end %.3f"
+              % (" ".join("%.3f" % ((t - t0) * 1e3) for t in trace), (t_g - t0) * 1e3, dt * 1e3), file=sys.stderr, flush=True)
+        t_s = time.perf_counter()
+        torch.cuda.synchronize()
+        print("[trace] a synchronize of the idle device: %.3f ms" % ((time.perf_counter() - t_s) * 1e3), file=sys.stderr, flush=True)
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -46,6 +46,35 @@ def compact(seg, cnt):
     return seg[keep]
 
 
+class RowSink:
+    """A rank's whole result as it accumulates: every batch's segments, unpadded, back to back in one array that is
+    allocated (and touched, so that no page of it is faulted in later) before the first batch arrives.  rows() and
+    counts() are what gather_compact takes."""
+
+    def __init__(self, max_frames, cap):
+        self._rows = np.zeros((max(1, int(max_frames) * int(cap)), 4), np.int32)
+        self._counts = np.zeros(max(1, int(max_frames)), np.int32)
+        self._k = self._n = 0
+
+    def append(self, seg, cnt):
+        """seg (n, cap, 4) padded segments and cnt (n,) counts of one batch (counts above cap are cut to cap)."""
+        cnt = np.minimum(np.asarray(cnt), np.asarray(seg).shape[1]).astype(np.int32, copy=False)
+        rows = compact(seg, cnt)
+        n, k = len(cnt), len(rows)
+        if self._n + n > len(self._counts) or self._k + k > len(self._rows):
+            raise ValueError("RowSink is full: %d frames / %d rows held, %d / %d more" % (self._n, self._k, n, k))
+        self._rows[self._k:self._k + k] = rows
+        self._counts[self._n:self._n + n] = cnt
+        self._k += k
+        self._n += n
+
+    def rows(self):
+        return self._rows[:self._k]
+
+    def counts(self):
+        return self._counts[:self._n]
+
+
 def gather_compact(rows, counts, dst=0, device=None):
     """Final gather of a rank's whole result to rank `dst` without the padding: `rows` (k, 4) int32 are the segments
     of all its frames back to back, `counts` (n,) int32 the segments per frame, in processing order (clip after clip).

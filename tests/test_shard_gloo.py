@@ -45,11 +45,16 @@ def _worker(rank, world, port, q):
     # the whole result in one unpadded gather, ranks holding different numbers of clips (3 clips over 2 ranks)
     mine3 = shard.clip_assignment(3, world, rank)
     rows, counts = [], []
+    sink = shard.RowSink(len(mine3) * NFRAMES, CAP)          # (the buffer the bench fills batch by batch)
     for c in mine3:
         seg, cnt = _clip_segments(c)
         rows.append(shard.compact(seg, cnt))
         counts.append(cnt)
-    got = shard.gather_compact(np.concatenate(rows), np.concatenate(counts), dst=0)
+        sink.append(seg[:NFRAMES // 2], cnt[:NFRAMES // 2])
+        sink.append(seg[NFRAMES // 2:], cnt[NFRAMES // 2:])
+    if mine3:
+        assert np.array_equal(sink.rows(), np.concatenate(rows)) and np.array_equal(sink.counts(), np.concatenate(counts))
+    got = shard.gather_compact(sink.rows(), sink.counts(), dst=0)
     if rank == 0:
         out["compact"] = {}
         for r, (rr, cc) in enumerate(got):
