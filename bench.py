@@ -42,8 +42,15 @@ def make_frames(seed, n, workers):
     import multiprocessing as mp
     jobs = [(seed, t) for t in range(n)]
     if workers > 1:
-        with mp.get_context("fork").Pool(workers) as pool:
+        # close + join, not the pool's context manager: that ends the workers with SIGTERM, and under rocprofv3 --pmc
+        # (whose library is already loaded, with its signal handler, when the workers are forked) a worker that catches
+        # it starts the profiler's finalisation and may never end
+        pool = mp.get_context("fork").Pool(workers)
+        try:
             frames = pool.map(_gen, jobs, chunksize=4)
+        finally:
+            pool.close()
+            pool.join()
     else:
         frames = [_gen(j) for j in jobs]
     return np.stack(frames)

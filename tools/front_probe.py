@@ -9,8 +9,12 @@ if os.environ.get("LANECV_SO"):
 batch = 256
 import multiprocessing as mp
 def gen(t): return synth.synth_road(1920, 1080, 100, t)
-with mp.get_context("fork").Pool(16) as pool:
+pool = mp.get_context("fork").Pool(16)      # (closed and joined, never terminated: see bench.make_frames)
+try:
     frames = np.stack(pool.map(gen, range(batch), chunksize=4))
+finally:
+    pool.close()
+    pool.join()
 for canny in [(100, 200), (100000, 200000)]:
     rec = dataclasses.replace(Recipe.north_star(1920, 1080), canny=canny, segments=False, accumulator=False)
     pipe = LanePipeline(1920, 1080, rec, max_batch=batch, nslots=1, seg_capacity=128, device=0, timing=True)

@@ -21,8 +21,12 @@ def gen(t):
     return synth.synth_road(W, H, 100, t)
 
 
-with mp.get_context("fork").Pool(16) as pool:
+pool = mp.get_context("fork").Pool(16)      # (closed and joined, never terminated: see bench.make_frames)
+try:
     frames = np.stack(pool.map(gen, range(B), chunksize=4))
+finally:
+    pool.close()
+    pool.join()
 base = Recipe.north_star(W, H)
 for name, rec in (("as it is", base), ("no accumulator", dataclasses.replace(base, accumulator=False)),
                   ("threshold nothing reaches", dataclasses.replace(base, threshold=100000))):

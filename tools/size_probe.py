@@ -9,8 +9,12 @@ from lanecv.pipeline import LanePipeline, Recipe
 w, h, batch, nslots, steps = (int(a) for a in sys.argv[1:6])
 import multiprocessing as mp
 def gen(t): return synth.synth_road(w, h, 100, t)
-with mp.get_context("fork").Pool(16) as pool:
+pool = mp.get_context("fork").Pool(16)      # (closed and joined, never terminated: see bench.make_frames)
+try:
     frames = np.stack(pool.map(gen, range(batch), chunksize=2))
+finally:
+    pool.close()
+    pool.join()
 rec = Recipe.north_star(w, h)
 pipe = LanePipeline(w, h, rec, max_batch=batch, nslots=nslots, seg_capacity=256, device=0, timing=True)
 ptr = pipe.upload(0, frames)
