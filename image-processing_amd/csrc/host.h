@@ -24,7 +24,9 @@ int fail(int code, const char *fmt, ...);
             return fail(LC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int RNG_TABLE = 32768, RNG_TABLE_MAX = 1 << 20;    // covers every point count the LDS fast path of HoughLinesP accepts
+// Length of the table of HoughLinesP's random numbers: at least every point count the forms of the LDS kernel with the points in
+// LDS accept, at most RNG_TABLE_MAX (the form that leaves the points in device memory takes as many points as the table is long).
+constexpr int RNG_TABLE = 32768, RNG_TABLE_MAX = 1 << 20;
 constexpr int MAX_DIM = 8192;       // 16.16 walk arithmetic and the packed (x | y << 16) points need this bound
 
 template <typename T>
