@@ -184,7 +184,8 @@ void launch_front(const uint8_t *src, size_t src_bytes, int in_kind, int code, b
 // chain of candidate pixels from an ROI pixel to a strong pixel further out passes through every ring (the distance
 // changes by at most one per step), and if the ROI pixel is not an edge already, every pixel of the chain inside the
 // rings is a weak pixel that stayed weak.  redo[f] = 1 iff such pixels connect ring 1 to ring 15 (8-neighbours, flooded
-// from all of ring 1's), or there are too many of them to tell; status[3] is raised then and bit 30 of rounds[f] set.
+// from all of ring 1's), or there are too many of them to tell; bit 30 of rounds[f] is set then (the host reads that, frame by frame: a word
+// for the whole batch would be written by this launch's workgroups on several XCDs, the clearing one among them).
 // ring_words: indices of the plane words that hold ring pixels; ring_code[b]: bit plane b of the ring number (0 = no ring).
 void launch_hysteresis(Geo g, int nframes, uint64_t *planeS, const uint64_t *planeW, uint32_t *wake, int *rounds,
                        hipStream_t st, int *status = nullptr, const int *only_frames = nullptr,

@@ -286,7 +286,6 @@ __device__ __forceinline__ void hysteresis_one_frame(const HystArgs &h, int f, i
     }
     if (threadIdx.x == 0) {
         if (h.ra.redo) h.ra.redo[f] = bad ? 1 : 0;
-        if (bad && st) st[3] = 1;        // (plain stores: the words may live in host memory)
         // bit 30 of the rounds word: the frame is, or (second pass over flagged frames) was, flagged
         if (h.rounds_out) h.rounds_out[f] = rounds | ((bad || h.only_frames) ? 0x40000000 : 0);
     }

@@ -491,7 +491,9 @@ int lc_pipe_submit_device(lc_pipe *pipe, int slot, const void *dev_bgr, int nfra
     int rc;
     if ((rc = get_slot(pipe, slot, &s))) return rc;
     if (!dev_bgr || nframes <= 0 || nframes > pipe->p.max_batch) return fail(LC_EINVAL, "submit: bad frames argument");
-    if (((uintptr_t)dev_bgr & 15) != 0) return fail(LC_EINVAL, "submit: device frames must be 16-byte aligned");
+    // (the slot's own input buffer, lc_pipe_input_device_ptr, is taken as it is: slots of a bank lie back to back in one buffer,
+    // and with an odd frame size the later ones start on a multiple of 4 only -- which is all the kernels need)
+    if (((uintptr_t)dev_bgr & 15) != 0 && dev_bgr != own_input(pipe, *s)) return fail(LC_EINVAL, "submit: device frames must be 16-byte aligned");
     if (s->busy) return fail(LC_EINVAL, "slot %d is still in flight; call lc_pipe_wait first", slot);
     s->nframes = nframes;
     s->input = (const uint8_t *)dev_bgr;
@@ -510,14 +512,18 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
     if (s->pending && (rc = launch_bank(pipe, s->bank))) return rc;      // its bank is not full: what is there goes now
     if (!s->tail_queued && (rc = finish_tail(pipe, false))) return rc;   // its hysteresis was waiting for a front launch to lead
     if ((rc = wait_event(pipe, slot, s->done))) return rc;
-    if (s->level < pipe->nlevels && s->h_status[3]) {
-        // Frames the ROI scheme could not settle from the units near the ROI were classified again in full.  Their full
-        // passes stored plane rows in units the level does not classify: cleared before the bank's next launch.  And a
-        // batch with many of them moves the pipeline a level out.
+    // Frames the ROI scheme could not settle from the units near the ROI: every frame's workgroup says so in its own word
+    // of the result block (bit 30 of the rounds word).  Not one word for the batch: the hysteresis launch also clears the
+    // batch's status words, from the first frame's workgroup, and two workgroups on different XCDs writing one word of
+    // device memory in one launch reach it in no particular order -- the flag of a later frame was lost that way.
+    int redone = 0;
+    if (s->level < pipe->nlevels)
+        for (int i = 0; i < s->nframes; i++) redone += (s->h_rounds[i] >> 30) & 1;
+    if (redone > 0) {
+        // They were (or are now) classified again in full.  Their full passes store plane rows in units the level does not
+        // classify: cleared before the bank's next launch.  And a batch with many of them moves the pipeline a level out.
         pipe->banks[s->bank].redone = true;
         pipe->redo_hold = 64;
-        int redone = 0;
-        for (int i = 0; i < s->nframes; i++) redone += (s->h_rounds[i] >> 30) & 1;
         const char *ob = getenv("LANECV_SKIP_OFF_BATCHES");         // diagnostics / tests; 0 = never move a level out
         const int off_batches = ob ? atoi(ob) : 256;
         if (4 * redone > s->nframes && off_batches > 0 && pipe->level <= s->level) {

@@ -412,6 +412,37 @@ def test_rows_above_the_roi_are_skipped_exactly(oracle, monkeypatch):
     pipe.close()
 
 
+@pytest.mark.parametrize("blur", [False, True])
+def test_a_later_frames_need_for_the_full_pass_is_not_lost(oracle, blur):
+    """The one frame of a batch that must be classified again in full sits BEHIND frames that need many hysteresis rounds
+    (1080p road frames without the blur): its workgroup finishes long before the first frame's, on another XCD.  A flag
+    word shared by the batch, cleared by the first frame's workgroup in the same launch, lost that frame's flag -- the
+    host now reads every frame's own word.  The frame's edges inside the ROI exist only through the rows far above it."""
+    import dataclasses
+    from lanecv import synth, _abi
+    from lanecv.pipeline import LanePipeline, Recipe
+    w, h = 1920, 1080
+    rec = dataclasses.replace(Recipe.simple(w, h), blur=blur, accumulator=True)
+    g = np.full((h, w), 60, np.int32)
+    g[:440, 1168:] += 120
+    g[440:, 1168:] += 45 if not blur else 60
+    faint = np.repeat(g[:, :, None], 3, axis=2).astype(np.uint8)
+    road = [synth.synth_road(w, h, seed=5, t=t) for t in (3, 4)]
+    for frames in ([road[0], faint], [road[0], road[1], faint], [faint, road[0]]):
+        pipe = LanePipeline(w, h, rec, max_batch=len(frames), nslots=1, seg_capacity=512)
+        frames = np.stack(frames)
+        pipe.submit(0, frames)
+        segs = pipe.collect(0)
+        masked = pipe.read(0, _abi.BUF_MASKED)
+        assert pipe.row_skip(0)[1] == 1
+        for i, f in enumerate(frames):
+            r = _oracle_frame(oracle, f, rec, pipe.roi)
+            assert (masked[i] == r["masked"]).all(), (len(frames), i)
+            got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
+            assert got.shape == r["segments"].shape and (got == r["segments"]).all(), (len(frames), i)
+        pipe.close()
+
+
 def test_roi_skipping_switches_off_and_on_again(oracle, monkeypatch):
     """A batch in which more than a quarter of the frames needed all units after all switches the ROI scheme off for a
     number of batches (here 2 instead of 256), which are classified in full from the start; the slot then skips again,
