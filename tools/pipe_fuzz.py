@@ -1,5 +1,6 @@
-"""Random batches through random pipelines against the oracle: sizes, recipes (north-star, simple, curve; triangle ROI or none),
-slot counts, batch sizes that change from batch to batch, frames from device memory, pinned and ordinary host memory, and a pool
+"""Random batches through random pipelines against the oracle: sizes, recipes (north-star, simple, curve, the colour-gated one;
+triangle, narrowed triangle, trapezoid or no ROI; sometimes the F1 car mask; thresholds of Canny varied), slot counts, the
+pipeline's readiness to move a level out, batch sizes that change from batch to batch, frames from device memory, pinned and ordinary host memory, and a pool
 of frames that provokes every rare path (faint edges across the ROI border, noise bands, all-black, checkerboards).  Masked
 map, accumulator and segments of every frame must equal the oracle's.   usage: python tools/pipe_fuzz.py [PIPELINES [SEED [ONLY]]]
 (ONLY: run just that pipeline of the sequence, e.g. one that reported a mismatch)"""
@@ -14,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "image-processing_amd")]
 import torch  # noqa: E402,F401  (before liblanecv.so)
 from lanecv import _abi, synth  # noqa: E402
-from lanecv.pipeline import LanePipeline, Recipe  # noqa: E402
+from lanecv.pipeline import LanePipeline, Recipe, narrow_triangle_roi, trapezoid_roi, f1_car_mask  # noqa: E402
 from oracle import lane_oracle as oracle  # noqa: E402
 
 oracle.build()
@@ -54,11 +55,28 @@ for k in range(npipes):
         continue
     rng = np.random.default_rng([seed0, k])
     w, h = [(640, 360), (960, 540), (1280, 720), (1920, 1080), (644, 362)][int(rng.integers(0, 5))]
-    rec = [Recipe.north_star, Recipe.simple, Recipe.curve][int(rng.integers(0, 3))](w, h)
+    rec = [Recipe.north_star, Recipe.simple, Recipe.curve, Recipe.hsv_gated][int(rng.integers(0, 4))](w, h)
     rec = dataclasses.replace(rec, accumulator=True)
-    if rng.random() < 0.2:
+    u = rng.random()
+    if u < 0.15:
         rec = dataclasses.replace(rec, roi_vertices=None, threshold=int(rec.threshold * 1.5))
+    elif u < 0.3:
+        rec = dataclasses.replace(rec, roi_vertices=narrow_triangle_roi(w, h))
+    elif u < 0.4:
+        rec = dataclasses.replace(rec, roi_vertices=trapezoid_roi(w, h), threshold=int(rec.threshold * 1.5))
+    if rng.random() < 0.15:
+        rec = dataclasses.replace(rec, car_mask=f1_car_mask(w, h))
+    if rng.random() < 0.3:
+        lo = int(rng.integers(20, 150))
+        rec = dataclasses.replace(rec, canny=(lo, lo + int(rng.integers(1, 200))))
     nslots, max_batch = int(rng.integers(1, 7)), int(rng.integers(1, 9))
+    if w <= 1280 and rng.random() < 0.15:
+        max_batch = int(rng.integers(9, 41))
+    off = [None, "0", "2"][int(rng.integers(0, 3))]          # batches the pipeline stays a level out (None: the default, 256)
+    if off is None:
+        os.environ.pop("LANECV_SKIP_OFF_BATCHES", None)
+    else:
+        os.environ["LANECV_SKIP_OFF_BATCHES"] = off
     if os.environ.get("PIPE_FUZZ_BLUR"):         # diagnostics: overrides that leave the random sequence alone
         rec = dataclasses.replace(rec, blur=os.environ["PIPE_FUZZ_BLUR"] == "1")
     nslots = int(os.environ.get("PIPE_FUZZ_SLOTS", nslots))
@@ -75,7 +93,8 @@ for k in range(npipes):
         for f in frames:
             if id(f) not in ref:
                 ref[id(f)] = oracle.lane_frame(f, rec.color_code, rec.blur, rec.canny[0], rec.canny[1], pipe.roi, rec.rho, rec.theta, rec.threshold,
-                                               rec.min_line_length, rec.max_line_gap, seg_cap=1 << 16, want_acc=True, want_segments=True)
+                                               rec.min_line_length, rec.max_line_gap, car_mask=rec.car_mask, seg_cap=1 << 16, want_acc=True,
+                                               want_segments=True, gate=rec.hsv_gate)
         # a frame with more edge points than the pipeline keeps per frame must fail its batch, and only then
         too_many = any(np.count_nonzero(ref[id(f)]["masked"]) > point_cap for f in frames)
         try:
@@ -102,12 +121,13 @@ for k in range(npipes):
                 if os.environ.get("PIPE_FUZZ_DUMP"):       # the frame and both masked maps, for a look offline
                     np.savez_compressed(os.environ["PIPE_FUZZ_DUMP"], frame=f, got=masked[i], ref=r["masked"], batch=np.stack(frames))
                 ys = np.nonzero((masked[i] != r["masked"]).any(axis=1))[0]
-                print("MISMATCH pipeline %d (%dx%d, blur %s, roi %s, %d slots, batch %d) batch %d slot %d how %d frame %d of %d (pool %d): masked %s acc %s "
+                print("MISMATCH pipeline %d (%dx%d, blur %s, roi %s, gate %s, car %s, canny %s, off %s, %d slots, batch %d) batch %d slot %d how %d frame %d of %d (pool %d): masked %s acc %s "
                       "segments %s; differing rows %s..%s (%d pixels), levels %s, redone %s"
-                      % (k, w, h, rec.blur, rec.roi_vertices is not None, nslots, max_batch, b, slot, how, i, len(frames), idx[i], okm, oka, oks,
+                      % (k, w, h, rec.blur, None if rec.roi_vertices is None else rec.roi_vertices.tolist(), rec.hsv_gate is not None, rec.car_mask is not None,
+                         rec.canny, off, nslots, max_batch, b, slot, how, i, len(frames), idx[i], okm, oka, oks,
                          ys.min() if len(ys) else -1, ys.max() if len(ys) else -1, int((masked[i] != r["masked"]).sum()), pipe.layout(), pipe.row_skip(slot)), flush=True)
 
-    for b in range(int(rng.integers(6, 14))):
+    for b in range(int(rng.integers(6, 20))):
         slot = b % nslots
         if len(inflight) == nslots:
             check(*inflight.pop(0))
