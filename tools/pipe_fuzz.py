@@ -55,6 +55,8 @@ for k in range(npipes):
         continue
     rng = np.random.default_rng([seed0, k])
     w, h = [(640, 360), (960, 540), (1280, 720), (1920, 1080), (644, 362)][int(rng.integers(0, 5))]
+    if os.environ.get("PIPE_FUZZ_SIZE"):          # e.g. 3840x2160
+        w, h = (int(v) for v in os.environ["PIPE_FUZZ_SIZE"].split("x"))
     rec = [Recipe.north_star, Recipe.simple, Recipe.curve, Recipe.hsv_gated][int(rng.integers(0, 4))](w, h)
     rec = dataclasses.replace(rec, accumulator=True)
     u = rng.random()
