@@ -84,7 +84,7 @@ for k in range(npipes):
     nslots = int(os.environ.get("PIPE_FUZZ_SLOTS", nslots))
     max_batch = max(max_batch, int(os.environ.get("PIPE_FUZZ_BATCH", 0)))
     force_how = int(os.environ.get("PIPE_FUZZ_HOW", -1))
-    pipe = LanePipeline(w, h, rec, max_batch=max_batch, nslots=nslots, seg_capacity=8192)
+    pipe = LanePipeline(w, h, rec, max_batch=max_batch, nslots=nslots, seg_capacity=8192, timing=os.environ.get("PIPE_FUZZ_TIMING") == "1")
     pool = pool_of_frames(w, h)
     point_cap = (max(1024, min(w * h, w * h // 8 + 1024)) + 3) & ~3
     ref = {}
