@@ -1,5 +1,5 @@
 """Random batches through random pipelines against the oracle: sizes, recipes (north-star, simple, curve, the colour-gated one;
-triangle, narrowed triangle, trapezoid or no ROI; sometimes the F1 car mask; thresholds of Canny varied), slot counts, the
+triangle, narrowed triangle, trapezoid or no ROI; sometimes the F1 car mask; thresholds of Canny varied), slot counts (taken and collected in random order), the
 pipeline's readiness to move a level out, batch sizes that change from batch to batch, frames from device memory, pinned and ordinary host memory, and a pool
 of frames that provokes every rare path (faint edges across the ROI border, noise bands, all-black, checkerboards).  Masked
 map, accumulator and segments of every frame must equal the oracle's.   usage: python tools/pipe_fuzz.py [PIPELINES [SEED [ONLY]]]
@@ -130,9 +130,13 @@ for k in range(npipes):
                          ys.min() if len(ys) else -1, ys.max() if len(ys) else -1, int((masked[i] != r["masked"]).sum()), pipe.layout(), pipe.row_skip(slot)), flush=True)
 
     for b in range(int(rng.integers(6, 20))):
-        slot = b % nslots
-        if len(inflight) == nslots:
-            check(*inflight.pop(0))
+        # slots are taken and collected in random order: any free slot, sometimes a wait before the slots are all in flight
+        # (a bank of several slots is then launched with what it holds), not always the oldest batch first
+        while len(inflight) == nslots or (inflight and rng.random() < 0.2):
+            check(*inflight.pop(int(rng.integers(0, len(inflight))) if rng.random() < 0.5 else 0))
+        busy = {it[0] for it in inflight}
+        free = [x for x in range(nslots) if x not in busy]
+        slot = free[int(rng.integers(0, len(free)))]
         n = int(rng.integers(1, max_batch + 1))
         idx = [int(j) for j in rng.integers(0, len(pool) if rng.random() < 0.5 else 5, n)]
         frames = [pool[j] for j in idx]
