@@ -43,6 +43,13 @@ struct FrameSet {
     __host__ __device__ bool first_of_part(int f) const { return per_part ? (f % per_part == 0 && count[f / per_part] > 0) : f == 0; }
 };
 
+// The frames of a launch that does flagged frames only, by number (relative to the launch's first frame): workgroup i does
+// frame f[i].  n = 0: a workgroup per frame, each looking its flag up.
+struct FlagList {
+    int n;
+    uint16_t f[62];
+};
+
 // Per-angle constants of HoughLinesProbabilistic, computed on the host exactly
 // as OpenCV's CPU code does (double cos/sin scaled by the float 1/rho, narrowed
 // to float; the walk step uses float division) and uploaded once.
@@ -237,10 +244,13 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
                       int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes = 0, bool only_flagged = false, int waves = 0,
-                      int status_frames = 0, const FrameSet *fs = nullptr, int device_state = 0);
+                      int status_frames = 0, const FrameSet *fs = nullptr, int device_state = 0, const FlagList *list = nullptr);
 // device_state 1: the form of the kernel that leaves the edge bits in the bit plane in device memory, 2: the point list as
 // well, permuted in place (with only_flagged, in this order between a launch of the ordinary form and the general kernel:
-// they take the frames whose mask words, or points, did not fit the LDS beside the accumulator)
+// they take the frames whose mask words, or points, did not fit the LDS beside the accumulator).  A frame the kernel
+// flags gets seg_count -1 until another kernel has done it: from those the caller makes `list`, so that a launch of
+// these forms is as many workgroups as there are frames to do -- each needs a whole CU's LDS, i.e. a CU that the
+// kernels of the batches in flight have left empty, whether it then finds its frame flagged or not.
 // status_frames: 0 = one block of status words for the launch; n = frames [k n, (k + 1) n) raise status + 8 k (a launch
 // over the batches of several pipeline slots, each with status words of its own)
 // waves: 8 or 4 wavefronts per frame (0: 4 with ppht_lds_half(), else 8).  Four is for launches that fill every CU twice

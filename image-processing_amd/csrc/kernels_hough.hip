@@ -803,7 +803,8 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
                                                    int32_t *__restrict__ seg_all, int seg_cap, int *__restrict__ seg_count,
                                                    int *__restrict__ status, int *__restrict__ fallback, int lds_points,
                                                    const uint32_t *__restrict__ rng_out, int lds_bytes,
-                                                   int32_t *__restrict__ acc_full, int only_flagged, int status_frames, FrameSet fs) {
+                                                   int32_t *__restrict__ acc_full, int only_flagged, int status_frames, FrameSet fs,
+                                                   FlagList fl) {
     constexpr int PPHT_THREADS = 64 * PPHT_WAVES;
     extern __shared__ __align__(16) uint32_t lds32[];
     __shared__ int progress;
@@ -817,7 +818,9 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     __shared__ uint32_t a_base[64], a_rfix[64], a_wid[64];
     __shared__ int a_rmin[64];
     __shared__ AngleEntry s_tab[64];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int f_ = blockIdx.x;
+    if constexpr (!MASK_LDS) { if (fl.n) f_ = fl.f[blockIdx.x]; }      // (the forms for flagged frames: the caller may name them)
+    const int f = f_, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!fs.has(f)) return;
     // one launch may cover the batches of several callers (parts of a pipeline slot): every status_frames frames have
     // status words of their own
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     }
     // status[4]: some frame is left to the general kernel -- which the caller may then launch only when this is raised
     if (n > lds_points) {                    // (the host's limit: what the biased 16-bit bins and the table of random numbers hold)
-        if (tid == 0) { fallback[f] = 3; status[4] = 1; }
+        if (tid == 0) { fallback[f] = 3; seg_count[f] = -1; status[4] = 1; }
         return;
     }
     Ppht c;
@@ -872,7 +875,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     const int nent = MASK_LDS ? nrows << wshift : 0;             // row-table entries, two words each
     const size_t rt_words = ((size_t)2 * nent + 3) & ~(size_t)3;
     if ((rt_off + rt_words + 4 * PPHT_BANDS) * 4 > (size_t)lds_bytes) {   // (the row table and the set-up's scratch alone do not fit)
-        if (tid == 0) { fallback[f] = 3; status[2] = 1; status[4] = 1; }
+        if (tid == 0) { fallback[f] = 3; seg_count[f] = -1; status[2] = 1; status[4] = 1; }
         return;
     }
     if (tid == 0) {
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     // holding two frames.
     const size_t mask_off = (acc_off + acc_words + 1) & ~(size_t)1;
     if ((mask_off + 2 * (size_t)maskwords) * 4 > (size_t)lds_bytes) {
-        if (tid == 0) { fallback[f] = 3; status[2] = 1; status[4] = 1; }   // does not fit: the general kernel (and its vote) take the frame
+        if (tid == 0) { fallback[f] = 3; seg_count[f] = -1; status[2] = 1; status[4] = 1; }   // does not fit: another kernel (and its vote) take the frame
         return;
     }
     if (tid == 0) fallback[f] = 0;
@@ -1345,7 +1348,7 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
                       const AngleEntry *tab, int numangle, int numrho, int threshold, int line_length, int line_gap,
                       int32_t *seg, int seg_cap, int *seg_count, int *status, int *flags, const uint32_t *rng_out,
                       int rng_len, int32_t *acc_full, hipStream_t st, int lds_bytes, bool only_flagged, int waves,
-                      int status_frames, const FrameSet *fs, int device_state) {
+                      int status_frames, const FrameSet *fs, int device_state, const FlagList *list) {
     // points, compact int16 accumulator and the mask spans in LDS; a frame whose set does not fit lds_bytes (the
     // kernel decides, per frame) is flagged.
     if (numangle > 64 || g.W > 4096) return false;   // one lane per angle; one map bit per 64-pixel word of a row
@@ -1358,9 +1361,9 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
         if (off) return true;
         if (device_state == 1) {
             if (optin8g.ensure(reinterpret_cast<const void *>(k_ppht_fast<8, false>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
-            hipLaunchKernelGGL((k_ppht_fast<8, false>), dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+            hipLaunchKernelGGL((k_ppht_fast<8, false>), dim3(list && list->n ? list->n : nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                                numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                               lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
+                               lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{}, list ? *list : FlagList{});
             return true;
         }
         // Points in device memory: their number is no longer bounded by the LDS.  A bin's count is also bounded by the
@@ -1371,9 +1374,9 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
         const long long stripe = (long long)std::max(g.W, g.H) * ((long long)std::floor(1.4143 * rho_est) + 3);
         if (stripe < LDS_BIAS - 8) lds_points = rng_len;
         if (optin8p.ensure(reinterpret_cast<const void *>(k_ppht_fast<8, false, false>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
-        hipLaunchKernelGGL((k_ppht_fast<8, false, false>), dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+        hipLaunchKernelGGL((k_ppht_fast<8, false, false>), dim3(list && list->n ? list->n : nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
+                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{}, list ? *list : FlagList{});
         return true;
     }
     static const char *wv_env = getenv("LANECV_PPHT_WAVES");           // diagnostics: 4 or 8 whatever the LDS size
@@ -1382,12 +1385,12 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
         if (optin4.ensure(reinterpret_cast<const void *>(k_ppht_fast<4>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
         hipLaunchKernelGGL(k_ppht_fast<4>, dim3(nframes), dim3(256), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
+                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{}, list ? *list : FlagList{});
     } else {
         if (optin8.ensure(reinterpret_cast<const void *>(k_ppht_fast<8>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
         hipLaunchKernelGGL(k_ppht_fast<8>, dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
-                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{});
+                           lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{}, list ? *list : FlagList{});
     }
     return true;
 }

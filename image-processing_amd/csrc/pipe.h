@@ -169,10 +169,12 @@ struct lc_pipe {
     // HoughLinesP with half a CU's LDS per frame, so that two frames -- of two batches, on two streams -- share a CU:
     // the kernel is one sequential wavefront per frame and leaves most of a CU idle.  For pipelines of two banks or more
     // and frame sizes whose working set usually fits (up to about 2.5 megapixels; 1080p road frames take 47 - 49 KiB).
-    // A frame that needs more falls to the slow general kernel; lc_pipe_wait sees it (status word 2) and the next
-    // `ppht_full_for` batches get a whole CU's LDS per frame again, after which the half size is tried anew.
+    // A frame that needs more is done again when its slot is waited for (lc_pipe_wait sees status word 2), with a whole
+    // CU's LDS; when that happens twice within a few launches the next `ppht_full_for` batches get a whole CU's LDS per
+    // frame from the start, after which the half size is tried anew.
     bool ppht_two_per_cu = false;
     int ppht_full_for = 0;
+    int ppht_flag_recent = 0;     // launches left in which a second flagged frame switches to whole-CU launches (lc_pipe_wait)
     int cu_count = 256;
     int shared_queues = 0;        // streams of this layout that found no hardware queue of their own (lc_pipe_create)
     hipEvent_t ev_base = nullptr; // recorded when stage times were first switched on

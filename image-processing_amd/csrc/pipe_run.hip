@@ -55,6 +55,7 @@ void enqueue_lines(lc_pipe *pp, Bank &bk, Slot *first, const Launch &L, hipStrea
                                 (pp->ppht_two_per_cu && pp->ppht_full_for == 0) ? ppht_lds_half() : 0, false,
                                 2 * L.nframes > pp->cu_count ? 0 : 8, p.max_batch, &L.fs);
         if (pp->ppht_full_for > 0) pp->ppht_full_for--;
+        if (pp->ppht_flag_recent > 0) pp->ppht_flag_recent--;
         // Frames the fast kernel cannot do (more points than fit a CU's LDS) are rare: it raises a status word of their
         // slot and lc_pipe_wait launches the general kernel then.  No packet that is not needed: every one on this
         // stream is on the critical path.  (More than 64 angles or frames wider than 4096: the general kernel for all,
@@ -546,11 +547,21 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         // first the LDS kernel's forms that read the mask, then the points as well, from device memory (frames whose points
         // are too scattered for their mask words to fit beside points and accumulator, or too many), then the general
         // kernel for what is still flagged
+        // (the frames to do, by number, from the marks the kernel left in their segment counts: a launch of as many
+        // workgroups, not one per frame of the batch -- each of them must find an empty CU first)
+        FlagList list{};
+        int nflagged = 0;
+        for (int i = 0; i < s->nframes; i++)
+            if (s->h_segcount[i] < 0) {
+                if (nflagged < (int)(sizeof(list.f) / sizeof(list.f[0]))) list.f[nflagged] = (uint16_t)i;
+                nflagged++;
+            }
+        list.n = nflagged <= (int)(sizeof(list.f) / sizeof(list.f[0])) ? nflagged : 0;
         for (int state = 1; state <= 2; state++)
             (void)launch_ppht_fast(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
                                    w.hg.numangle, w.hg.numrho, p.threshold, pipe->line_length, pipe->line_gap, w.r_seg + fo * w.seg_cap * 4, w.seg_cap,
                                    w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, w.rng_out.p, w.rng_len,
-                                   vote_fused ? w.acc_full.p + fo * accn : nullptr, ps, 0, true, 8, 0, nullptr, state);
+                                   vote_fused ? w.acc_full.p + fo * accn : nullptr, ps, 0, true, 8, 0, nullptr, state, &list);
         launch_ppht_general(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
                             w.hg.numangle, w.hg.numrho, w.acc_ppht.p + fo * accn, p.threshold, pipe->line_length, pipe->line_gap,
                             w.r_seg + fo * w.seg_cap * 4, w.seg_cap, w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, ps,
@@ -564,7 +575,14 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         if ((rc = wait_event(pipe, slot, s->done))) return rc;
     }
     s->busy = false;
-    if (p.want_segments && s->h_status[2]) pipe->ppht_full_for = 64;   // a frame outgrew half a CU's LDS (see lc_pipe)
+    if (p.want_segments && s->h_status[2]) {       // a frame outgrew half a CU's LDS (see lc_pipe)
+        // Once in a while: the frame was done again just now, with a whole CU's LDS, and that was that.  Twice within a few
+        // launches: the content is like that, and every batch would pay for its flagged frames when it is waited for --
+        // whole-CU launches for the next 64, which cost every batch a little instead.  LANECV_PPHT_FULL_AT_ONCE=1: at the first.
+        static const bool at_once = getenv("LANECV_PPHT_FULL_AT_ONCE") != nullptr;
+        if (pipe->ppht_flag_recent > 0 || at_once) pipe->ppht_full_for = 64;
+        pipe->ppht_flag_recent = 24;
+    }
     if (p.want_segments || p.want_accumulator || p.want_points) {
         if (s->h_status[0])
             return fail(LC_ECAP, "a frame holds more edge points than the pipeline keeps per frame (%d): its point list, accumulator and "

@@ -18,7 +18,7 @@ SETTINGS = [
     {"LANECV_NO_ROW_SKIP": "1"}, {"LANECV_NO_STRIP_SHIFT": "1"},
     {"LANECV_PPHT_WAVES": "8"},
     {"LANECV_PPHT_LDS_KB": "49.5"}, {"LANECV_PPHT_LDS_KB": "16"},
-    {"LANECV_PPHT_TWO_PER_CU": "0"}, {"LANECV_NO_SCATTER_KERNEL": "1"},
+    {"LANECV_PPHT_TWO_PER_CU": "0"}, {"LANECV_NO_SCATTER_KERNEL": "1"}, {"LANECV_PPHT_FULL_AT_ONCE": "1"},
     {"LANECV_VOTE_FUSED": "0"},
     {"LANECV_NO_GROUPS": "1", "LANECV_RESULT_COPY": "1"},
     {"LANECV_LINES_STREAMS": "1"}, {"LANECV_LINES_PRIORITY": "0"}, {"LANECV_POST_STREAM": "0", "LANECV_TAIL_STREAMS": "0"},
