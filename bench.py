@@ -437,6 +437,11 @@ def main():
         run([jobs[k % len(jobs)] for k in range(args.warmup)])
     note("warm-up done")
     stages, kept = [], shard.RowSink(sum(n for _, n in jobs), SEG_CAP)      # the rank's result buffer: allocated before the clock starts
+    # (as timeit does: Python's collector off while the clock runs -- a full collection is a pause of tens of milliseconds that
+    # has nothing to do with the path measured)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     run(jobs, stages, kept)
@@ -448,6 +453,7 @@ def main():
         t_g = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if trace is not None:
         print("[trace] waits returned at (ms): %s; gathered at %.3f; end %.3f"
               % (" ".join("%.3f" % ((t - t0) * 1e3) for t in trace), (t_g - t0) * 1e3, dt * 1e3), file=sys.stderr, flush=True)
