@@ -84,7 +84,9 @@ for k in range(npipes):
     nslots = int(os.environ.get("PIPE_FUZZ_SLOTS", nslots))
     max_batch = max(max_batch, int(os.environ.get("PIPE_FUZZ_BATCH", 0)))
     force_how = int(os.environ.get("PIPE_FUZZ_HOW", -1))
-    pipe = LanePipeline(w, h, rec, max_batch=max_batch, nslots=nslots, seg_capacity=8192, timing=os.environ.get("PIPE_FUZZ_TIMING") == "1")
+    keep = bool(rng.random() < 0.2)                           # gray, blurred and pre-ROI edge maps kept and compared too
+    pipe = LanePipeline(w, h, rec, max_batch=max_batch, nslots=nslots, seg_capacity=8192, keep_intermediates=keep,
+                        timing=os.environ.get("PIPE_FUZZ_TIMING") == "1")
     pool = pool_of_frames(w, h)
     point_cap = (max(1024, min(w * h, w * h // 8 + 1024)) + 3) & ~3
     ref = {}
@@ -112,8 +114,21 @@ for k in range(npipes):
             print("MISSING LC_ECAP pipeline %d" % k, flush=True)
             return
         masked, acc = pipe.read(slot, _abi.BUF_MASKED), pipe.read(slot, _abi.BUF_ACC)
+        npts = pipe.read(slot, _abi.BUF_NPOINTS)
+        inter = {}
+        if keep:
+            inter = {"gray": pipe.read(slot, _abi.BUF_GRAY), "edges": pipe.read(slot, _abi.BUF_EDGES)}
+            if rec.blur:
+                inter["blur"] = pipe.read(slot, _abi.BUF_BLUR)
         for i, f in enumerate(frames):
             r = ref[id(f)]
+            for name, v in inter.items():
+                if not (v[i] == r[name]).all():
+                    bad += 1
+                    print("MISMATCH pipeline %d: %s of frame %d" % (k, name, i), flush=True)
+            if npts[i] != np.count_nonzero(r["masked"]):
+                bad += 1
+                print("MISMATCH pipeline %d: the point count of frame %d" % (k, i), flush=True)
             got = np.zeros((0, 4), np.int32) if segs[i] is None else segs[i].reshape(-1, 4)
             okm, oka = (masked[i] == r["masked"]).all(), (acc[i] == r["acc"]).all()
             oks = got.shape == r["segments"].shape and (got == r["segments"]).all()
