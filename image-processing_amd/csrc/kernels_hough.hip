@@ -819,7 +819,8 @@ __global__ __launch_bounds__(64 * PPHT_WAVES) void k_ppht_fast(Geo g, const uint
     __shared__ int a_rmin[64];
     __shared__ AngleEntry s_tab[64];
     int f_ = blockIdx.x;
-    if constexpr (!MASK_LDS) { if (fl.n) f_ = fl.f[blockIdx.x]; }      // (the forms for flagged frames: the caller may name them)
+    // (the launches over flagged frames -- eight wavefronts, a whole CU's LDS -- may name their frames; the four-wavefront kernel of the shared-CU launches never does)
+    if constexpr (!MASK_LDS || PPHT_WAVES == 8) { if (fl.n) f_ = fl.f[blockIdx.x]; }
     const int f = f_, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!fs.has(f)) return;
     // one launch may cover the batches of several callers (parts of a pipeline slot): every status_frames frames have
@@ -1388,7 +1389,7 @@ bool launch_ppht_fast(Geo g, int nframes, uint32_t *nz, int nz_cap, const int *n
                            lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{}, list ? *list : FlagList{});
     } else {
         if (optin8.ensure(reinterpret_cast<const void *>(k_ppht_fast<8>), (size_t)PPHT_LDS_MAX) != hipSuccess) return false;
-        hipLaunchKernelGGL(k_ppht_fast<8>, dim3(nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
+        hipLaunchKernelGGL(k_ppht_fast<8>, dim3(list && list->n ? list->n : nframes), dim3(512), lds_bytes, st, g, nz, nz_cap, npoints, rowplane, tab, numangle,
                            numrho, threshold, line_length, line_gap, seg, seg_cap, seg_count, status, flags, lds_points, rng_out,
                            lds_bytes, acc_full, only_flagged ? 1 : 0, status_frames, fs ? *fs : FrameSet{}, list ? *list : FlagList{});
     }

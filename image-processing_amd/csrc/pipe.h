@@ -145,8 +145,10 @@ struct lc_pipe {
     int nlevels = 0, level = 0, level_hold = 0;
     // Launches queue the second pass over flagged frames (the front kernel again, hysteresis again: two launches that
     // find nothing to do when no frame is flagged) only while flagged frames are about -- for this many launches after
-    // lc_pipe_wait last saw one.  Otherwise a flagged frame is made up for when its slot is waited for (enqueue_repair).
+    // lc_pipe_wait saw the second batch with one within a few launches.  Otherwise a flagged frame is made up for when its
+    // slot is waited for (enqueue_repair).
     int redo_hold = 0;
+    int redo_recent = 0;          // launches left in which another flagged frame starts the hold (lc_pipe_wait)
     DevBuf<int> ones;
     // What the front kernel reads of a frame at the tightest level, as a few windows (rows [r0, r1), bytes [b0, b1) of each):
     // per row segment the columns of its needed strips and the rows the units warm up and drain on.  Frames submitted from

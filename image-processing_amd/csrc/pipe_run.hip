@@ -255,6 +255,7 @@ int launch_bank(lc_pipe *pp, int bi) {
         eager = eager && s.rows_from == 0 && !s.windowed;
     }
     static const bool always_eager = getenv("LANECV_EAGER_REDO") && getenv("LANECV_EAGER_REDO")[0] == '1';   // diagnostics
+    if (pp->redo_recent > 0) pp->redo_recent--;
     if (pp->redo_hold > 0) pp->redo_hold--;
     else if (!always_eager) eager = false;
     if (from_host) {
@@ -524,7 +525,11 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
         // They were (or are now) classified again in full.  Their full passes store plane rows in units the level does not
         // classify: cleared before the bank's next launch.  And a batch with many of them moves the pipeline a level out.
         pipe->banks[s->bank].redone = true;
-        pipe->redo_hold = 64;
+        // the launches queue the second pass themselves only when such frames come again within a few launches: the two
+        // extra launches cost every batch a tenth of its tail (the hysteresis workgroups that look the flags up wait for
+        // room like any other), an isolated frame is cheaper made up for here
+        if (pipe->redo_recent > 0) pipe->redo_hold = 64;
+        pipe->redo_recent = 24;
         const char *ob = getenv("LANECV_SKIP_OFF_BATCHES");         // diagnostics / tests; 0 = never move a level out
         const int off_batches = ob ? atoi(ob) : 256;
         if (4 * redone > s->nframes && off_batches > 0 && pipe->level <= s->level) {
@@ -557,7 +562,11 @@ int lc_pipe_wait(lc_pipe *pipe, int slot, int32_t *seg_xyxy, int32_t *seg_count)
                 nflagged++;
             }
         list.n = nflagged <= (int)(sizeof(list.f) / sizeof(list.f[0])) ? nflagged : 0;
-        for (int state = 1; state <= 2; state++)
+        // Three tries, each with a whole CU's LDS: everything in LDS as in the ordinary launch (a frame that only outgrew HALF
+        // a CU's LDS: walks along lines through a mask in LDS are the fastest), the mask in device memory, the points too.
+        // (A first try with the 79 KiB that are free beside one frame of a shared-CU launch, so that the workgroup need not
+        // wait for an empty CU, changed nothing measurable: the frame's own HoughLinesP is the time.)
+        for (int state = (list.n && pipe->ppht_two_per_cu) ? 0 : 1; state <= 2; state++)
             (void)launch_ppht_fast(w.g, s->nframes, w.nz.p + fo * w.nz_cap, w.nz_cap, w.npoints.p + fo, w.rowplane.p + fo * w.g.rowplane_words(), w.tab.p,
                                    w.hg.numangle, w.hg.numrho, p.threshold, pipe->line_length, pipe->line_gap, w.r_seg + fo * w.seg_cap * 4, w.seg_cap,
                                    w.r_segcount + fo, w.r_status + 8 * s->pos, w.fallback.p + fo, w.rng_out.p, w.rng_len,

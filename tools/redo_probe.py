@@ -18,8 +18,8 @@ from lanecv import synth  # noqa: E402
 from lanecv.pipeline import LanePipeline, Recipe  # noqa: E402
 
 W, H, B, NS, STEPS = 1920, 1080, 256, 4, 120
-if os.environ.get("REDO_PROBE_NOGC"):      # Python's collector off: a full collection is a 35 ms pause, a third of a run of this length
-    import gc
+if not os.environ.get("REDO_PROBE_GC"):    # Python's collector off (REDO_PROBE_GC=1 leaves it on): a full collection is a 35 ms
+    import gc                              # pause, a third of a run of this length, and lands in the fourth or so pipeline of a process
     gc.disable()
 shares = [float(v) for v in sys.argv[1:]] or [0.0, 0.02, 0.1, 0.5]
 rec = Recipe.north_star(W, H)
